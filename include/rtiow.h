@@ -1,0 +1,142 @@
+/* rtiow.h -- C-ABI of librtiow_hip.so: the MI355X (gfx950) `render` hot path of the
+ * RayTracingInOneWeekend tracer, as a drop-in for the launch sequence in the reference's
+ *   src/GlobalFloatCUDAInOneWeekend/main.cu  (fp32)  and
+ *   src/GlobalDoubleCUDAInOneWeekend/main.cu (fp64).
+ *
+ * The reference has no FFI: it launches its kernels inline.  Each entry point below replaces
+ * one phase of that inline sequence (cited as main.cu:LINE, relative to
+ * /root/reference/src/GlobalFloatCUDAInOneWeekend/ unless noted) so that a host `main` keeps
+ * the reference's ordering and timing semantics.  INTEGRATION.md shows the host-side binding.
+ *
+ * Conventions: plain C, no C++ types, no exceptions.  Every function returns an int:
+ * 0 on success, otherwise the hipError_t value of the failing runtime call (or a negative
+ * RTIOW_E_* code for argument errors); rtiow_last_error_string() gives the text that the
+ * reference's CUDA_SAFE_CALL (main.cu:14-21) would have printed.  The caller owns host
+ * memory; the library owns device memory behind the opaque handle.  A handle is not
+ * thread-safe.  One handle == one GPU; multi-GPU jobs use one handle per rank (process).
+ */
+#ifndef RTIOW_H
+#define RTIOW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTIOW_ABI_VERSION 1
+
+#define RTIOW_E_BADARG   (-1)
+#define RTIOW_E_STATE    (-2)   /* call order violated (e.g. render before set_scene) */
+#define RTIOW_E_NOMEM    (-3)
+
+/* MaterialType (material.h:11-15). */
+#define RTIOW_LAMBERTIAN 0
+#define RTIOW_METAL      1
+#define RTIOW_DIELECTRIC 2
+
+/* Scene-table source selected for the sphere loop (the AMD analogue of the reference's
+ * global / constant / texture variants, README.md:7-12). */
+#define RTIOW_SCENE_LDS    0    /* sphere list staged into LDS per workgroup (default) */
+#define RTIOW_SCENE_SCALAR 1    /* wave-uniform scalar loads through the scalar cache  */
+
+typedef struct rtiow_handle_s* rtiow_handle;
+
+/* The fields of `struct camera` that `render` reads (camera.h:10-30), produced by
+ * camera::initialize (camera.h:33-68).  Scalars are in the handle's precision: pass
+ * rtiow_camera_f32 to a 32-bit handle and rtiow_camera_f64 to a 64-bit one. */
+typedef struct {
+    int32_t img_width, img_height, samples_per_pixel, max_depth;
+    float   pixel_samples_scale;
+    float   center[3], pixel00_loc[3], pixel_delta_u[3], pixel_delta_v[3];
+    float   defocus_angle;
+    float   defocus_disk_u[3], defocus_disk_v[3];
+} rtiow_camera_f32;
+
+typedef struct {
+    int32_t img_width, img_height, samples_per_pixel, max_depth;
+    double  pixel_samples_scale;
+    double  center[3], pixel00_loc[3], pixel_delta_u[3], pixel_delta_v[3];
+    double  defocus_angle;
+    double  defocus_disk_u[3], defocus_disk_v[3];
+} rtiow_camera_f64;
+
+typedef struct {
+    double   rng_init_ms;        /* last rtiow_init_rng kernel time (HIP events)           */
+    double   render_ms;          /* last rtiow_render kernel time (HIP events)             */
+    uint64_t primary_rays;       /* local_rows * width * samples of the last render        */
+    int32_t  local_rows;         /* rows of the image this handle renders                  */
+    int32_t  num_spheres;        /* spheres uploaded (invalid slots already dropped)       */
+    int32_t  block_x, block_y;   /* thread-block shape used by the last render             */
+    int32_t  vgprs, sgprs;       /* register use of the render kernel variant (0: unknown) */
+    int32_t  lds_bytes;          /* dynamic+static LDS per workgroup of the last render    */
+    int32_t  scene_source;       /* RTIOW_SCENE_*                                          */
+} rtiow_stats;
+
+/* ---- lifetime -------------------------------------------------------------------------
+ * rtiow_create replaces cudaSetDevice(0) + event creation (main.cu:81-92).
+ * precision is 32 (GlobalFloat) or 64 (GlobalDouble). */
+int rtiow_abi_version(void);
+int rtiow_create(int device, int precision, rtiow_handle* out);
+int rtiow_destroy(rtiow_handle h);                                   /* main.cu:384-388 */
+const char* rtiow_last_error_string(rtiow_handle h);                 /* main.cu:14-21   */
+
+/* Run on an existing hipStream_t (e.g. torch's current stream) instead of the handle's own. */
+int rtiow_set_stream(rtiow_handle h, void* hip_stream);
+
+/* ---- scene: replaces cudaMalloc/cudaMemcpy of materials+spheres+world and the two
+ * pointer fix-up kernels (main.cu:301-321).  Arrays are host arrays in the handle's
+ * precision T:  center_radius[4n] = {cx,cy,cz,r}, albedo_fuzz[4n] = {r,g,b,fuzz},
+ * refraction_index[n]; type[n] = RTIOW_*; valid[n] (may be NULL = all valid): slots the
+ * reference leaves default-constructed (skipped grid cells, main.cu:168) are dropped. */
+int rtiow_set_scene(rtiow_handle h, int n, const void* center_radius, const void* albedo_fuzz,
+                    const void* refraction_index, const int32_t* type, const int32_t* valid);
+
+/* ---- camera: replaces passing `cam` by value to render (main.cu:335). */
+int rtiow_set_camera(rtiow_handle h, const void* camera /* rtiow_camera_f32 | _f64 */);
+
+/* ---- multi-GPU row sharding (new; the reference is single-GPU, main.cu:81).
+ * The image is cut into strips of strip_rows rows dealt round-robin: this handle renders
+ * the strips s with s % nranks == rank.  Default (0,1,8) = the whole image.  RNG streams
+ * are keyed by the GLOBAL pixel index, so the assembled image does not depend on nranks. */
+int rtiow_set_shard(rtiow_handle h, int rank, int nranks, int strip_rows);
+int rtiow_local_rows(rtiow_handle h, int* rows);
+/* Global row index of each local row (rows_out has rtiow_local_rows entries). */
+int rtiow_local_row_map(rtiow_handle h, int32_t* rows_out);
+
+/* ---- RNG: replaces cudaMalloc(rand_states) + init_rng<<<>>> (main.cu:326-330,
+ * rtweekend.h:43-50): XORWOW, curand_init(seed, global_pixel_index, 0). */
+int rtiow_init_rng(rtiow_handle h, uint64_t seed);
+
+/* ---- render: replaces render<<<dimGrid,dimBlock>>> + sync (main.cu:334-341).
+ * threads_per_block_row is the reference's --threads (block = T x T pixels, main.cu:137-139;
+ * the grid is ceil-divided, unlike main.cu:137-138).  0 selects the library's own tiling.
+ * kernel_ms (may be NULL) receives the HIP-event time around the kernel only; passing NULL
+ * makes the call asynchronous on the handle's stream. */
+int rtiow_render(rtiow_handle h, int threads_per_block_row, float* kernel_ms);
+
+/* Framebuffer: `vec3 pixel_buffer[]` (main.cu:133-134), local_rows x width x 3 T, row-major.
+ * By default device memory owned by the library; rtiow_bind_framebuffer lets the caller
+ * supply device memory (e.g. a torch tensor that torch.distributed will gather). */
+int rtiow_bind_framebuffer(rtiow_handle h, void* device_ptr, size_t bytes);
+int rtiow_framebuffer_device_ptr(rtiow_handle h, void** device_ptr, size_t* bytes);
+/* D2H copy of the local rows (replaces the managed-memory read at main.cu:373). */
+int rtiow_read_framebuffer(rtiow_handle h, void* host_rgb, size_t bytes);
+
+/* ---- knobs / introspection */
+int rtiow_set_scene_source(rtiow_handle h, int scene_source /* RTIOW_SCENE_* */);
+int rtiow_get_stats(rtiow_handle h, rtiow_stats* out);
+int rtiow_synchronize(rtiow_handle h);
+
+/* ---- test hooks (used by tests/ only): device RNG states after rtiow_init_rng, as
+ * local_pixels x 6 uint32 {v0..v4,d}; and elementwise device arithmetic probes that the
+ * parity tests compare bit-for-bit with the host (op: 0 a/b, 1 sqrt(a), 2 fma(a,b,c),
+ * 3 uniform(u32 a -> T), 4 a*b+c unfused). */
+int rtiow_debug_read_rng(rtiow_handle h, uint32_t* host_states, size_t count_words);
+int rtiow_debug_ops(rtiow_handle h, int op, size_t n, const void* a, const void* b, const void* c, void* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTIOW_H */

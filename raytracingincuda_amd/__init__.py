@@ -1,0 +1,17 @@
+"""raytracingincuda_amd -- MI355X (gfx950) native `render` hot path of RayTracingInOneWeekend.
+
+Host-side mirror (Python over the C-ABI in include/rtiow.h and include/rtiow_host.h) of the
+launch sequence of the reference's src/Global{Float,Double}CUDAInOneWeekend/main.cu.
+The HIP library is mandatory: nothing here falls back to a CPU path.
+"""
+from .api import (  # noqa: F401
+    LAMBERTIAN, METAL, DIELECTRIC, SCENE_LDS, SCENE_SCALAR,
+    RtiowError, Renderer, build_scene, camera, compact_scene, ppm_filename, format_ppm, write_ppm,
+    place_rows, scene_slots, load_hip_library, load_host_library, lib_paths,
+)
+
+__all__ = [
+    "LAMBERTIAN", "METAL", "DIELECTRIC", "SCENE_LDS", "SCENE_SCALAR", "RtiowError", "Renderer",
+    "build_scene", "camera", "compact_scene", "ppm_filename", "format_ppm", "write_ppm", "place_rows",
+    "scene_slots", "load_hip_library", "load_host_library", "lib_paths",
+]

@@ -1,0 +1,361 @@
+"""ctypes mirror of the C-ABI (include/rtiow.h, include/rtiow_host.h).
+
+The call sequence a user writes mirrors the phases of the reference's main()
+(/root/reference/src/GlobalFloatCUDAInOneWeekend/main.cu:37-400):
+
+    cam   = camera(32, width, height, samples, bounces)      # main.cu:100-124
+    scene = build_scene(scene_id, 32)                        # main.cu:148-296
+    r = Renderer(device=0, precision=32)                     # main.cu:81-92
+    r.set_camera(cam); r.set_scene(scene)                    # main.cu:301-321
+    r.init_rng(1227)                                         # main.cu:326-330
+    ms  = r.render(threads=8)                                # main.cu:334-341
+    rgb = r.read_framebuffer()                               # main.cu:373
+    write_ppm(ppm_filename(32, scene_id, ...), rgb)          # main.cu:349-379
+
+There is no CPU fallback: if librtiow_hip.so is missing or no GPU is visible the calls
+raise.  (The CPU oracle lives in oracle/ and is test infrastructure only.)
+"""
+import ctypes
+import os
+
+import numpy as np
+
+LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
+SCENE_LDS, SCENE_SCALAR = 0, 1
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIBDIR = os.path.join(_PKG, "lib")
+
+
+class RtiowError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("rtiow error %d: %s" % (code, message))
+        self.code = code
+
+
+class CameraF32(ctypes.Structure):
+    _fields_ = [("img_width", ctypes.c_int32), ("img_height", ctypes.c_int32),
+                ("samples_per_pixel", ctypes.c_int32), ("max_depth", ctypes.c_int32),
+                ("pixel_samples_scale", ctypes.c_float),
+                ("center", ctypes.c_float * 3), ("pixel00_loc", ctypes.c_float * 3),
+                ("pixel_delta_u", ctypes.c_float * 3), ("pixel_delta_v", ctypes.c_float * 3),
+                ("defocus_angle", ctypes.c_float),
+                ("defocus_disk_u", ctypes.c_float * 3), ("defocus_disk_v", ctypes.c_float * 3)]
+
+
+class CameraF64(ctypes.Structure):
+    _fields_ = [("img_width", ctypes.c_int32), ("img_height", ctypes.c_int32),
+                ("samples_per_pixel", ctypes.c_int32), ("max_depth", ctypes.c_int32),
+                ("pixel_samples_scale", ctypes.c_double),
+                ("center", ctypes.c_double * 3), ("pixel00_loc", ctypes.c_double * 3),
+                ("pixel_delta_u", ctypes.c_double * 3), ("pixel_delta_v", ctypes.c_double * 3),
+                ("defocus_angle", ctypes.c_double),
+                ("defocus_disk_u", ctypes.c_double * 3), ("defocus_disk_v", ctypes.c_double * 3)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("rng_init_ms", ctypes.c_double), ("render_ms", ctypes.c_double),
+                ("primary_rays", ctypes.c_uint64), ("local_rows", ctypes.c_int32),
+                ("num_spheres", ctypes.c_int32), ("block_x", ctypes.c_int32), ("block_y", ctypes.c_int32),
+                ("vgprs", ctypes.c_int32), ("sgprs", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
+                ("scene_source", ctypes.c_int32)]
+
+
+# Every symbol include/rtiow.h declares (tests check that the built library exports them all).
+HIP_SYMBOLS = [
+    "rtiow_abi_version", "rtiow_create", "rtiow_destroy", "rtiow_last_error_string", "rtiow_set_stream",
+    "rtiow_set_scene", "rtiow_set_camera", "rtiow_set_shard", "rtiow_local_rows", "rtiow_local_row_map",
+    "rtiow_init_rng", "rtiow_render", "rtiow_bind_framebuffer", "rtiow_framebuffer_device_ptr",
+    "rtiow_read_framebuffer", "rtiow_set_scene_source", "rtiow_get_stats", "rtiow_synchronize",
+    "rtiow_debug_read_rng", "rtiow_debug_ops",
+]
+HOST_SYMBOLS = [
+    "rtiow_host_scene_slots", "rtiow_host_build_scene", "rtiow_host_camera", "rtiow_host_ppm_filename",
+    "rtiow_host_write_ppm", "rtiow_host_format_ppm", "rtiow_host_place_rows",
+]
+
+_hip = None
+_host = None
+
+
+def lib_paths():
+    return {"hip": os.path.join(_LIBDIR, "librtiow_hip.so"), "host": os.path.join(_LIBDIR, "librtiow_host.so")}
+
+
+def load_host_library():
+    global _host
+    if _host is None:
+        path = lib_paths()["host"]
+        if not os.path.exists(path):
+            raise RtiowError(-100, "%s not built; run `python -m raytracingincuda_amd.build`" % path)
+        lib = ctypes.CDLL(path)
+        vp, i32p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)
+        lib.rtiow_host_scene_slots.argtypes = [ctypes.c_int]
+        lib.rtiow_host_build_scene.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, i32p, i32p]
+        lib.rtiow_host_camera.argtypes = [ctypes.c_int] * 5 + [vp]
+        lib.rtiow_host_ppm_filename.argtypes = [ctypes.c_int] * 7 + [ctypes.c_char_p, ctypes.c_size_t]
+        lib.rtiow_host_write_ppm.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+        lib.rtiow_host_format_ppm.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_char_p,
+                                              ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        lib.rtiow_host_place_rows.argtypes = [ctypes.c_int] * 6 + [vp, vp]
+        _host = lib
+    return _host
+
+
+def load_hip_library():
+    """Load librtiow_hip.so.  Raises loudly when it is missing: there is no fallback path."""
+    global _hip
+    if _hip is None:
+        path = lib_paths()["hip"]
+        if not os.path.exists(path):
+            raise RtiowError(-100, "%s not built; run `python -m raytracingincuda_amd.build`" % path)
+        lib = ctypes.CDLL(path)
+        vp, H = ctypes.c_void_p, ctypes.c_void_p
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        lib.rtiow_abi_version.argtypes = []
+        lib.rtiow_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(H)]
+        lib.rtiow_destroy.argtypes = [H]
+        lib.rtiow_last_error_string.argtypes = [H]
+        lib.rtiow_last_error_string.restype = ctypes.c_char_p
+        lib.rtiow_set_stream.argtypes = [H, vp]
+        lib.rtiow_set_scene.argtypes = [H, ctypes.c_int, vp, vp, vp, i32p, i32p]
+        lib.rtiow_set_camera.argtypes = [H, vp]
+        lib.rtiow_set_shard.argtypes = [H, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        lib.rtiow_local_rows.argtypes = [H, ctypes.POINTER(ctypes.c_int)]
+        lib.rtiow_local_row_map.argtypes = [H, i32p]
+        lib.rtiow_init_rng.argtypes = [H, ctypes.c_uint64]
+        lib.rtiow_render.argtypes = [H, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+        lib.rtiow_bind_framebuffer.argtypes = [H, vp, ctypes.c_size_t]
+        lib.rtiow_framebuffer_device_ptr.argtypes = [H, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
+        lib.rtiow_read_framebuffer.argtypes = [H, vp, ctypes.c_size_t]
+        lib.rtiow_set_scene_source.argtypes = [H, ctypes.c_int]
+        lib.rtiow_get_stats.argtypes = [H, ctypes.POINTER(Stats)]
+        lib.rtiow_synchronize.argtypes = [H]
+        lib.rtiow_debug_read_rng.argtypes = [H, ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t]
+        lib.rtiow_debug_ops.argtypes = [H, ctypes.c_int, ctypes.c_size_t, vp, vp, vp, vp]
+        _hip = lib
+    return _hip
+
+
+def _dtype(precision):
+    if precision == 32:
+        return np.float32
+    if precision == 64:
+        return np.float64
+    raise ValueError("precision must be 32 or 64")
+
+
+def scene_slots(scene_id):
+    return load_host_library().rtiow_host_scene_slots(int(scene_id))
+
+
+def build_scene(scene_id, precision=32):
+    """World creation, main.cu:148-296.  Returns a dict of numpy arrays in slot order
+    (center_radius [n,4], albedo_fuzz [n,4], refraction_index [n], type [n], valid [n])."""
+    lib = load_host_library()
+    dt = _dtype(precision)
+    n = lib.rtiow_host_scene_slots(int(scene_id))
+    cr = np.zeros((n, 4), dt); af = np.zeros((n, 4), dt); ri = np.zeros(n, dt)
+    ty = np.zeros(n, np.int32); va = np.zeros(n, np.int32)
+    got = lib.rtiow_host_build_scene(int(scene_id), precision, cr.ctypes.data, af.ctypes.data, ri.ctypes.data,
+                                     ty.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                     va.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    if got != n:
+        raise RtiowError(got, "rtiow_host_build_scene failed")
+    return {"scene_id": int(scene_id), "precision": precision, "center_radius": cr, "albedo_fuzz": af,
+            "refraction_index": ri, "type": ty, "valid": va}
+
+
+def compact_scene(scene):
+    """Drop the slots the reference leaves default-constructed (main.cu:168)."""
+    keep = scene["valid"] != 0
+    out = dict(scene)
+    for k in ("center_radius", "albedo_fuzz", "refraction_index", "type", "valid"):
+        out[k] = np.ascontiguousarray(scene[k][keep])
+    return out
+
+
+def camera(precision, width, height, samples, bounces):
+    """camera configuration + camera::initialize (main.cu:100-124, camera.h:33-68)."""
+    lib = load_host_library()
+    cam = CameraF64() if precision == 64 else CameraF32()
+    _dtype(precision)
+    rc = lib.rtiow_host_camera(precision, int(width), int(height), int(samples), int(bounces), ctypes.addressof(cam))
+    if rc:
+        raise RtiowError(rc, "rtiow_host_camera: bad arguments")
+    return cam
+
+
+def ppm_filename(precision, scene_id, width, height, samples, bounces, threads):
+    buf = ctypes.create_string_buffer(256)
+    rc = load_host_library().rtiow_host_ppm_filename(precision, scene_id, width, height, samples, bounces, threads, buf, 256)
+    if rc:
+        raise RtiowError(rc, "rtiow_host_ppm_filename failed")
+    return buf.value.decode()
+
+
+def _rgb_precision(rgb):
+    if rgb.dtype == np.float32:
+        return 32
+    if rgb.dtype == np.float64:
+        return 64
+    raise ValueError("rgb must be float32 or float64")
+
+
+def format_ppm(rgb):
+    """P3 text of an [H, W, 3] image, main.cu:368-379."""
+    rgb = np.ascontiguousarray(rgb)
+    h, w = rgb.shape[0], rgb.shape[1]
+    lib = load_host_library()
+    n = ctypes.c_size_t(0)
+    p = _rgb_precision(rgb)
+    rc = lib.rtiow_host_format_ppm(p, w, h, rgb.ctypes.data, None, 0, ctypes.byref(n))
+    if rc:
+        raise RtiowError(rc, "rtiow_host_format_ppm failed")
+    buf = ctypes.create_string_buffer(n.value)
+    rc = lib.rtiow_host_format_ppm(p, w, h, rgb.ctypes.data, buf, n.value, ctypes.byref(n))
+    if rc:
+        raise RtiowError(rc, "rtiow_host_format_ppm failed")
+    return buf.raw[:n.value]
+
+
+def write_ppm(path, rgb):
+    rgb = np.ascontiguousarray(rgb)
+    rc = load_host_library().rtiow_host_write_ppm(os.fsencode(path), _rgb_precision(rgb), rgb.shape[1], rgb.shape[0], rgb.ctypes.data)
+    if rc:
+        raise RtiowError(rc, "Could not open file for writing: %s" % path)
+
+
+def place_rows(full_rgb, local_rgb, rank, nranks, strip_rows):
+    """Scatter one shard's rows (rtiow_set_shard order) into the full [H, W, 3] image."""
+    assert full_rgb.flags.c_contiguous and local_rgb.flags.c_contiguous and full_rgb.dtype == local_rgb.dtype
+    rc = load_host_library().rtiow_host_place_rows(_rgb_precision(full_rgb), full_rgb.shape[1], full_rgb.shape[0],
+                                                   rank, nranks, strip_rows, local_rgb.ctypes.data, full_rgb.ctypes.data)
+    if rc:
+        raise RtiowError(rc, "rtiow_host_place_rows: bad arguments")
+    return full_rgb
+
+
+class Renderer:
+    """One GPU's render state behind the C-ABI handle (include/rtiow.h)."""
+
+    def __init__(self, device=0, precision=32):
+        self._lib = load_hip_library()
+        self.precision = precision
+        self.dtype = _dtype(precision)
+        self._h = ctypes.c_void_p()
+        rc = self._lib.rtiow_create(int(device), int(precision), ctypes.byref(self._h))
+        if rc:
+            self._h = None
+            raise RtiowError(rc, "rtiow_create(device=%d) failed -- is a GPU visible?" % device)
+        self.width = self.height = 0
+
+    def _check(self, rc):
+        if rc:
+            raise RtiowError(rc, self._lib.rtiow_last_error_string(self._h).decode(errors="replace"))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rtiow_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, hip_stream):
+        self._check(self._lib.rtiow_set_stream(self._h, ctypes.c_void_p(int(hip_stream))))
+
+    def set_scene(self, scene):
+        dt = self.dtype
+        cr = np.ascontiguousarray(scene["center_radius"], dt)
+        af = np.ascontiguousarray(scene["albedo_fuzz"], dt)
+        ri = np.ascontiguousarray(scene["refraction_index"], dt)
+        ty = np.ascontiguousarray(scene["type"], np.int32)
+        va = np.ascontiguousarray(scene["valid"], np.int32) if scene.get("valid") is not None else None
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        self._check(self._lib.rtiow_set_scene(self._h, len(ty), cr.ctypes.data, af.ctypes.data, ri.ctypes.data,
+                                              ty.ctypes.data_as(i32p), va.ctypes.data_as(i32p) if va is not None else None))
+
+    def set_camera(self, cam):
+        want = CameraF64 if self.precision == 64 else CameraF32
+        if not isinstance(cam, want):
+            raise TypeError("camera precision does not match the renderer")
+        self._check(self._lib.rtiow_set_camera(self._h, ctypes.addressof(cam)))
+        self.width, self.height = cam.img_width, cam.img_height
+
+    def set_shard(self, rank, nranks, strip_rows=8):
+        self._check(self._lib.rtiow_set_shard(self._h, rank, nranks, strip_rows))
+
+    def set_scene_source(self, source):
+        self._check(self._lib.rtiow_set_scene_source(self._h, source))
+
+    @property
+    def local_rows(self):
+        n = ctypes.c_int(0)
+        self._check(self._lib.rtiow_local_rows(self._h, ctypes.byref(n)))
+        return n.value
+
+    def local_row_map(self):
+        rows = np.zeros(self.local_rows, np.int32)
+        if len(rows):
+            self._check(self._lib.rtiow_local_row_map(self._h, rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
+        return rows
+
+    def init_rng(self, seed=1227):
+        self._check(self._lib.rtiow_init_rng(self._h, ctypes.c_uint64(seed)))
+
+    def render(self, threads=8, sync=True):
+        """render<<<>>> + sync; returns the HIP-event kernel time in ms (None when sync=False)."""
+        if sync:
+            ms = ctypes.c_float(0)
+            self._check(self._lib.rtiow_render(self._h, int(threads), ctypes.byref(ms)))
+            return ms.value
+        self._check(self._lib.rtiow_render(self._h, int(threads), None))
+        return None
+
+    def bind_framebuffer(self, device_ptr, nbytes):
+        self._check(self._lib.rtiow_bind_framebuffer(self._h, ctypes.c_void_p(int(device_ptr)), nbytes))
+
+    def framebuffer_device_ptr(self):
+        p = ctypes.c_void_p()
+        n = ctypes.c_size_t(0)
+        self._check(self._lib.rtiow_framebuffer_device_ptr(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def read_framebuffer(self):
+        out = np.empty((self.local_rows, self.width, 3), self.dtype)
+        if out.size:
+            self._check(self._lib.rtiow_read_framebuffer(self._h, out.ctypes.data, out.nbytes))
+        return out
+
+    def synchronize(self):
+        self._check(self._lib.rtiow_synchronize(self._h))
+
+    def stats(self):
+        st = Stats()
+        self._check(self._lib.rtiow_get_stats(self._h, ctypes.byref(st)))
+        return {name: getattr(st, name) for name, _ in Stats._fields_}
+
+    # -- test hooks
+    def debug_read_rng(self):
+        n = self.local_rows * self.width
+        out = np.zeros((n, 6), np.uint32)
+        self._check(self._lib.rtiow_debug_read_rng(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), out.size))
+        return out
+
+    def debug_ops(self, op, a, b=None, c=None):
+        a = np.ascontiguousarray(a, self.dtype)
+        b = np.ascontiguousarray(b if b is not None else a, self.dtype)
+        c = np.ascontiguousarray(c if c is not None else a, self.dtype)
+        out = np.empty_like(a)
+        self._check(self._lib.rtiow_debug_ops(self._h, op, a.size, a.ctypes.data, b.ctypes.data, c.ctypes.data, out.ctypes.data))
+        return out

@@ -1,0 +1,89 @@
+"""Build every native artefact of the package in-tree.
+
+  lib/librtiow_hip.so    HIP kernels + device C-ABI (include/rtiow.h), hipcc --offload-arch=gfx950
+  lib/librtiow_host.so   host-side scene/camera/PPM C interface (include/rtiow_host.h), g++
+  bin/global-float-hip-raytrace, bin/global-double-hip-raytrace   drop-in executables
+  bin/ppm_diff, bin/scaled_ppm_diff, bin/csv_avg                  harness tools (when present)
+
+hipcc cross-compiles for gfx950 without a GPU.  Run as `python -m raytracingincuda_amd.build`.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+INC = os.path.join(ROOT, "include")
+LIB = os.path.join(PKG, "lib")
+BIN = os.path.join(PKG, "bin")
+
+# Floating-point contract of the render path: no implicit contraction, IEEE
+# correctly rounded fp32 divide/sqrt, denormals kept.
+HIP_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
+    "-fno-fast-math", "-I" + INC,
+]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-I" + INC]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (needed to build librtiow_hip.so for gfx950)")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd, verbose):
+    if verbose:
+        print("+", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIB, exist_ok=True)
+    os.makedirs(BIN, exist_ok=True)
+    headers = [os.path.join(INC, "rtiow.h"), os.path.join(INC, "rtiow_host.h")]
+    me = os.path.abspath(__file__)
+
+    hip_src = os.path.join(CSRC, "rtiow_hip.hip")
+    hip_so = os.path.join(LIB, "librtiow_hip.so")
+    if force or _newer(hip_so, [hip_src, me] + headers):
+        _run([_hipcc()] + HIP_FLAGS + ["-o", hip_so, hip_src], verbose)
+
+    host_src = os.path.join(CSRC, "host", "rtiow_host.cpp")
+    host_so = os.path.join(LIB, "librtiow_host.so")
+    if force or _newer(host_so, [host_src, me] + headers):
+        _run(["g++"] + HOST_FLAGS + ["-shared", "-o", host_so, host_src], verbose)
+
+    main_src = os.path.join(CSRC, "host", "main.cpp")
+    for prec, name in ((32, "global-float-hip-raytrace"), (64, "global-double-hip-raytrace")):
+        exe = os.path.join(BIN, name)
+        if force or _newer(exe, [main_src, hip_so, host_so, me] + headers):
+            _run(["g++"] + HOST_FLAGS + ["-DRTIOW_PRECISION=%d" % prec, "-o", exe, main_src,
+                  "-L" + LIB, "-lrtiow_hip", "-lrtiow_host", "-Wl,-rpath,$ORIGIN/../lib",
+                  "-Wl,-rpath-link," + LIB, "-Wl,-rpath-link,/opt/rocm/lib"], verbose)
+
+    tools = os.path.join(CSRC, "tools")
+    if os.path.isdir(tools):
+        for src in sorted(os.listdir(tools)):
+            if not src.endswith(".cpp"):
+                continue
+            exe = os.path.join(BIN, src[:-4])
+            path = os.path.join(tools, src)
+            if force or _newer(exe, [path, me]):
+                _run(["g++", "-O2", "-std=c++17", "-o", exe, path], verbose)
+    return {"hip": hip_so, "host": host_so, "bin": BIN}
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

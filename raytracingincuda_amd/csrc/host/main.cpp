@@ -1,0 +1,174 @@
+// main.cpp -- global-float-hip-raytrace / global-double-hip-raytrace.
+//
+// Drop-in for the reference executables built from
+//   /root/reference/src/GlobalFloatCUDAInOneWeekend/main.cu   (RTIOW_PRECISION=32)
+//   /root/reference/src/GlobalDoubleCUDAInOneWeekend/main.cu  (RTIOW_PRECISION=64)
+// Same flags, defaults, exit codes, stdout line ("%15.8f,%15.8f\n" = render_only_ms,
+// end_to_end_ms), output file name and P3 format, so the reference's *_benchmark.sh,
+// process.py and ppm_diff tooling work unchanged.  The phases below are in the order of
+// main.cu:37-400; each device phase is one call into the C-ABI (include/rtiow.h).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rtiow.h"
+#include "rtiow_host.h"
+
+#ifndef RTIOW_PRECISION
+#define RTIOW_PRECISION 32
+#endif
+
+namespace {
+
+struct Options {
+    bool have_scene = false, help = false;
+    int scene_id = 0, width = 320, height = 192, samples = 10, bounces = 25, threads = 8;   // main.cu:45-54
+    int scene_source = RTIOW_SCENE_LDS;
+    bool stats = false;
+};
+
+const char* kUsage =
+    "Super Raytrace: Raytracing with HIP\n"
+    "Usage:\n"
+    "  ./hip-raytrace [OPTION...]\n"
+    "\n"
+    "      --scene_id arg  ID of the scene to render\n"
+    "      --width arg     Width of the output image (default: 320)\n"
+    "      --height arg    Height of the output image (default: 192)\n"
+    "      --samples arg   Number of samples per pixel (default: 10)\n"
+    "      --bounces arg   Maximum number of ray bounces (default: 25)\n"
+    "      --threads arg   Number of threads per 2-D thread block row. (default: \n"
+    "                      8)\n"
+    "  -h, --help          Print usage\n";
+
+[[noreturn]] void parse_abort(const std::string& what) {
+    // cxxopts throws on a bad option and the reference does not catch: std::terminate.
+    std::fprintf(stderr, "terminate called after throwing an instance of 'cxxopts::exceptions::parsing'\n  what():  %s\n", what.c_str());
+    std::abort();
+}
+
+int parse_int(const std::string& name, const std::string& text) {
+    char* end = nullptr;
+    const long v = std::strtol(text.c_str(), &end, 10);
+    if (text.empty() || *end != '\0') parse_abort("Argument '" + text + "' failed to parse");
+    (void)name;
+    return (int)v;
+}
+
+Options parse(int argc, char** argv) {
+    Options o;
+    for (int k = 1; k < argc; ++k) {
+        std::string arg = argv[k];
+        if (arg == "-h" || arg == "--help") { o.help = true; continue; }
+        if (arg.rfind("--", 0) != 0) parse_abort("Option '" + arg + "' does not exist");
+        std::string name = arg.substr(2), value;
+        const size_t eq = name.find('=');
+        bool have_value = false;
+        if (eq != std::string::npos) { value = name.substr(eq + 1); name = name.substr(0, eq); have_value = true; }
+        if (name == "stats") { o.stats = true; continue; }
+        const bool known = name == "scene_id" || name == "width" || name == "height" || name == "samples" ||
+                           name == "bounces" || name == "threads" || name == "scene_source";
+        if (!known) parse_abort("Option '" + name + "' does not exist");
+        if (!have_value) {
+            if (k + 1 >= argc) parse_abort("Option '" + name + "' is missing an argument");
+            value = argv[++k];
+        }
+        if (name == "scene_source") {
+            if (value == "lds") o.scene_source = RTIOW_SCENE_LDS;
+            else if (value == "scalar") o.scene_source = RTIOW_SCENE_SCALAR;
+            else parse_abort("Argument '" + value + "' failed to parse");
+            continue;
+        }
+        const int v = parse_int(name, value);
+        if (name == "scene_id") { o.scene_id = v; o.have_scene = true; }
+        else if (name == "width") o.width = v;
+        else if (name == "height") o.height = v;
+        else if (name == "samples") o.samples = v;
+        else if (name == "bounces") o.bounces = v;
+        else o.threads = v;
+    }
+    return o;
+}
+
+// main.cu:14-21: message on stderr, exit with the error code, stdout left as it is.
+void check(rtiow_handle h, int rc) {
+    if (rc == 0) return;
+    std::fprintf(stderr, "%s\n", h ? rtiow_last_error_string(h) : "HIP_SAFE_CALL: device initialisation failed");
+    std::exit(rc);
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    const Options opt = parse(argc, argv);                                   // main.cu:39-77
+    if (opt.help) { std::fputs(kUsage, stdout); std::fputs("\n", stdout); return 0; }
+    if (!opt.have_scene) {
+        std::fputs("Error: --scene_id is required.\n", stderr);
+        std::fputs(kUsage, stdout); std::fputs("\n", stdout);
+        return 1;
+    }
+    const int precision = RTIOW_PRECISION;
+    const size_t elem = precision == 64 ? 8 : 4;
+
+    rtiow_handle h = nullptr;
+    int rc = rtiow_create(0, precision, &h);                                 // main.cu:81-92
+    if (rc) { std::fprintf(stderr, "HIP_SAFE_CALL: cannot open device 0 (error %d)\n", rc); return rc; }
+    const auto e2e_start = std::chrono::steady_clock::now();                 // main.cu:95
+
+    // image/camera configuration (main.cu:100-124)
+    rtiow_camera_f32 cam32; rtiow_camera_f64 cam64;
+    void* cam = precision == 64 ? (void*)&cam64 : (void*)&cam32;
+    if (rtiow_host_camera(precision, opt.width, opt.height, opt.samples, opt.bounces, cam) != 0) {
+        std::fputs("Error: invalid image size.\n", stderr);
+        return 1;
+    }
+    check(h, rtiow_set_camera(h, cam));
+    check(h, rtiow_set_scene_source(h, opt.scene_source));
+
+    // world creation (main.cu:142-321)
+    const int slots = rtiow_host_scene_slots(opt.scene_id);
+    std::vector<unsigned char> cr(elem * 4 * slots), af(elem * 4 * slots), ri(elem * slots);
+    std::vector<int32_t> type(slots), valid(slots);
+    rtiow_host_build_scene(opt.scene_id, precision, cr.data(), af.data(), ri.data(), type.data(), valid.data());
+    check(h, rtiow_set_scene(h, slots, cr.data(), af.data(), ri.data(), type.data(), valid.data()));
+
+    // device RNG (main.cu:324-330, rtweekend.h:49)
+    check(h, rtiow_init_rng(h, 1227));
+
+    // render, kernel-only timing (main.cu:332-345)
+    float render_ms = 0;
+    check(h, rtiow_render(h, opt.threads, &render_ms));
+    std::printf("%15.8f,", (double)render_ms);
+    std::fflush(stdout);
+
+    // .ppm output (main.cu:347-379)
+    char name[256];
+    rtiow_host_ppm_filename(precision, opt.scene_id, opt.width, opt.height, opt.samples, opt.bounces, opt.threads, name, sizeof name);
+    std::vector<unsigned char> rgb(elem * 3 * (size_t)opt.width * opt.height);
+    check(h, rtiow_read_framebuffer(h, rgb.data(), rgb.size()));
+    if (rtiow_host_write_ppm(name, precision, opt.width, opt.height, rgb.data()) != 0) {
+        std::fprintf(stderr, "Error: Could not open file for writing: %s\n", name);
+        return -1;
+    }
+
+    rtiow_stats st;
+    std::memset(&st, 0, sizeof st);
+    rtiow_get_stats(h, &st);
+    check(h, rtiow_destroy(h));                                              // main.cu:384-391
+    const auto e2e_stop = std::chrono::steady_clock::now();                  // main.cu:394
+    const double e2e_ms = std::chrono::duration<double, std::milli>(e2e_stop - e2e_start).count();
+    std::printf("%15.8f\n", e2e_ms);
+
+    if (opt.stats) {   // extra metrics go to stderr so that stdout stays the reference's CSV fragment
+        const double rays = (double)opt.width * opt.height * opt.samples;
+        std::fprintf(stderr,
+                     "{\"mrays_per_s\": %.3f, \"render_ms\": %.6f, \"rng_init_ms\": %.6f, \"spheres\": %d, \"block\": [%d, %d], "
+                     "\"vgprs\": %d, \"lds_bytes\": %d, \"scene_source\": \"%s\"}\n",
+                     render_ms > 0 ? rays / render_ms / 1e3 : 0.0, (double)render_ms, st.rng_init_ms, st.num_spheres,
+                     st.block_x, st.block_y, st.vgprs, st.lds_bytes, st.scene_source == RTIOW_SCENE_LDS ? "lds" : "scalar");
+    }
+    return 0;
+}

@@ -1,0 +1,828 @@
+// rtiow_hip.hip -- the only translation unit compiled for gfx950.
+//
+// Hand-written HIP for the `render` hot path of the reference tracer
+// (/root/reference/src/GlobalFloatCUDAInOneWeekend/camera.h:130-172 and the device
+// functions it calls: hittable.h:40-98, material.h:38-89, vec3.h:109-138,
+// rtweekend.h:32-50), plus the C-ABI declared in include/rtiow.h.
+//
+// Design (DESIGN.md has the long form):
+//  * one lane = one pixel; one wave64 = one 8x8 pixel tile (coherent primary rays);
+//  * the samples x bounces nest is FLATTENED into a per-lane state machine: one loop
+//    iteration = one path segment for every live lane; a lane whose path ends accumulates
+//    and starts its next sample at once, so lanes never idle waiting for the longest path
+//    of the current sample.  Per-pixel RNG consumption order is unchanged, so the image is
+//    bit-identical to the nested form;
+//  * sphere geometry {cx,cy,cz,r^2} is staged into LDS once per workgroup (or read with
+//    wave-uniform scalar loads, RTIOW_SCENE_SCALAR); per-ray invariants (|d|^2) are hoisted;
+//    the loop keeps only (t, index) of the nearest hit and completes the hit record once;
+//  * per-pixel XORWOW streams (curand_init(1227, global_pixel_index, 0) semantics) are
+//    created by a separate untimed kernel and read as SoA; they are not written back;
+//  * no MFMA: this is branchy scalar FP, not a contraction.
+//
+// Floating-point contract (identical to oracle/rtiow_oracle.cpp, so kernel == oracle bit for
+// bit): IEEE correctly-rounded + - * / sqrt, explicit fma() only where written, compiled
+// with -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt, denormals preserved.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rtiow.h"
+
+namespace {
+
+// =====================================================================================
+// XORWOW: state in registers; skip-ahead matrices built on the host.
+// =====================================================================================
+struct Rng { uint32_t v0, v1, v2, v3, v4, d; };
+
+__device__ __forceinline__ uint32_t rng_next(Rng& s) {
+    uint32_t t = s.v0 ^ (s.v0 >> 2);
+    s.v0 = s.v1; s.v1 = s.v2; s.v2 = s.v3; s.v3 = s.v4;
+    s.v4 = (s.v4 ^ (s.v4 << 4)) ^ (t ^ (t << 1));
+    s.d += 362437u;
+    return s.v4 + s.d;
+}
+
+template <class T> struct Real;
+template <> struct Real<float> {
+    // curand_uniform: (0,1]
+    static __device__ __forceinline__ float uniform(Rng& s) {
+        uint32_t x = rng_next(s);
+        return __builtin_fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+    }
+    static __device__ __forceinline__ float from_u32(uint32_t x) {
+        return __builtin_fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+    }
+    static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+    static __device__ __forceinline__ float sqrt(float a) { return __builtin_sqrtf(a); }
+    static __device__ __forceinline__ float fmin(float a, float b) { return __builtin_fminf(a, b); }
+    static __device__ __forceinline__ float fabs(float a) { return __builtin_fabsf(a); }
+    static constexpr float near_zero = 1e-6f;   // vec3.h:50
+    static constexpr float ruv_eps = 1e-8f;     // vec3.h:124
+};
+template <> struct Real<double> {
+    // curand_uniform_double (XORWOW): 53 bits from two draws
+    static __device__ __forceinline__ double uniform(Rng& s) {
+        uint32_t x = rng_next(s);
+        uint32_t y = rng_next(s);
+        uint64_t z = (uint64_t)x ^ ((uint64_t)y << 21);
+        return __builtin_fma((double)z, 1.1102230246251565e-16, 5.5511151231257827e-17);
+    }
+    static __device__ __forceinline__ double from_u32(uint32_t x) {
+        return __builtin_fma((double)x, 1.1102230246251565e-16, 5.5511151231257827e-17);
+    }
+    static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+    static __device__ __forceinline__ double sqrt(double a) { return __builtin_sqrt(a); }
+    static __device__ __forceinline__ double fmin(double a, double b) { return __builtin_fmin(a, b); }
+    static __device__ __forceinline__ double fabs(double a) { return __builtin_fabs(a); }
+    static constexpr double near_zero = 1e-8;   // GlobalDouble vec3.h:50
+    static constexpr double ruv_eps = 1e-160;   // GlobalDouble vec3.h:125
+};
+
+constexpr int XW_BITS = 160;
+constexpr int XW_WORDS = 5;
+constexpr int XW_JUMPS = 32;                         // subsequence index bits supported
+constexpr size_t XW_MAT_WORDS = (size_t)XW_BITS * XW_WORDS;
+
+// jump: [XW_JUMPS][160][5]; column `bit` of matrix b is the state reached from basis bit.
+// All lanes walk the same (b, bit) order, so the column reads are wave-uniform scalar loads.
+__global__ void __launch_bounds__(256)
+rng_init_kernel(uint32_t* __restrict__ states, const uint32_t* __restrict__ jump, uint32_t d0,
+                uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t s4,
+                int W, int H, int local_rows, int rank, int nranks, int strip_rows) {
+    const int npix = W * local_rows;
+    const int lp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lp >= npix) return;
+    const int jl = lp / W, i = lp - jl * W;
+    const int j = ((jl / strip_rows) * nranks + rank) * strip_rows + (jl % strip_rows);
+    const uint32_t seq = (uint32_t)(j * W + i);       // camera.h:134 pixel_index, rtweekend.h:49
+    uint32_t v[XW_WORDS] = {s0, s1, s2, s3, s4};
+    for (int b = 0; b < XW_JUMPS; ++b) {
+        if (!((seq >> b) & 1u)) continue;
+        const uint32_t* m = jump + (size_t)b * XW_MAT_WORDS;
+        uint32_t o[XW_WORDS] = {0, 0, 0, 0, 0};
+        for (int w = 0; w < XW_WORDS; ++w) {
+            const uint32_t word = v[w];
+            for (int bit = 0; bit < 32; ++bit) {
+                const uint32_t mask = 0u - ((word >> bit) & 1u);
+                const uint32_t* c = m + (size_t)(w * 32 + bit) * XW_WORDS;
+#pragma unroll
+                for (int k = 0; k < XW_WORDS; ++k) o[k] ^= c[k] & mask;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < XW_WORDS; ++k) v[k] = o[k];
+    }
+    // SoA so that the render kernel's 6 loads per lane are coalesced.
+    states[0 * (size_t)npix + lp] = v[0];
+    states[1 * (size_t)npix + lp] = v[1];
+    states[2 * (size_t)npix + lp] = v[2];
+    states[3 * (size_t)npix + lp] = v[3];
+    states[4 * (size_t)npix + lp] = v[4];
+    states[5 * (size_t)npix + lp] = d0;               // 2^67*k draws leave the Weyl counter unchanged
+    (void)H;
+}
+
+// =====================================================================================
+// render
+// =====================================================================================
+template <class T> struct V3 { T x, y, z; };
+
+template <class T> struct RenderParams {
+    int W, H, S, B;
+    T pixel_samples_scale;
+    V3<T> center, pixel00, du, dv;
+    T defocus_angle;
+    V3<T> ddu, ddv;
+    int n;
+    const T* __restrict__ geom_a;     // [n][4] cx,cy,cz,r*r       (sphere loop)
+    const T* __restrict__ geom_b;     // [n][4] cx,cy,cz,1/r       (hit completion)
+    const T* __restrict__ mat_a;      // [n][4] albedo rgb, fuzz
+    const T* __restrict__ mat_b;      // [n][2] ri, 1/ri
+    const int* __restrict__ mat_type; // [n]
+    const uint32_t* __restrict__ rng; // [6][npix_local] SoA
+    T* __restrict__ fb;               // [local_rows][W][3]
+    int local_rows, rank, nranks, strip_rows;
+    int bx, by;                       // tile (block) shape in pixels
+    int wave_tiles;                   // 1: lanes of a wave form 8x8 tiles inside the block
+};
+
+#define RT_FMA(a, b, c) Real<T>::fma((a), (b), (c))
+
+template <class T> __device__ __forceinline__ T dot3(V3<T> u, V3<T> v) {   // vec3.h:93-97
+    return RT_FMA(u.z, v.z, RT_FMA(u.y, v.y, u.x * v.x));
+}
+template <class T> __device__ __forceinline__ V3<T> madd3(T t, V3<T> v, V3<T> w) {   // w + t*v
+    return {RT_FMA(t, v.x, w.x), RT_FMA(t, v.y, w.y), RT_FMA(t, v.z, w.z)};
+}
+template <class T> __device__ __forceinline__ V3<T> scale3(T t, V3<T> v) { return {t * v.x, t * v.y, t * v.z}; }
+template <class T> __device__ __forceinline__ V3<T> unit3(V3<T> v) {       // vec3.h:105-107, 89-91
+    T inv = (T)1 / Real<T>::sqrt(dot3(v, v));
+    return scale3(inv, v);
+}
+template <class T> __device__ __forceinline__ V3<T> reflect3(V3<T> v, V3<T> n) {   // vec3.h:129-131
+    T k = (T)2 * dot3(v, n);
+    return madd3(-k, n, v);
+}
+template <class T> __device__ __forceinline__ V3<T> random_unit_vector(Rng& s) {   // vec3.h:117-127
+    for (;;) {
+        T x = RT_FMA(Real<T>::uniform(s), (T)2, (T)-1);
+        T y = RT_FMA(Real<T>::uniform(s), (T)2, (T)-1);
+        T z = RT_FMA(Real<T>::uniform(s), (T)2, (T)-1);
+        V3<T> p = {x, y, z};
+        T lensq = dot3(p, p);
+        if (Real<T>::ruv_eps < lensq && lensq <= (T)1) {
+            T inv = (T)1 / Real<T>::sqrt(lensq);
+            return scale3(inv, p);
+        }
+    }
+}
+
+// One primary ray: camera.h:145-155 (+ :73-76, vec3.h:109-115).  Also returns the y
+// component of the PRIMARY ray's unit direction, all the sky term needs (camera.h:121).
+template <class T>
+__device__ __forceinline__ void gen_primary(const RenderParams<T>& p, int i, int j, Rng& s,
+                                            V3<T>& O, V3<T>& D, T& sky_uy) {
+    T ox = Real<T>::uniform(s) - (T)0.5;
+    T oy = Real<T>::uniform(s) - (T)0.5;
+    T fi = (T)i + ox, fj = (T)j + oy;
+    V3<T> ps = madd3(fj, p.dv, madd3(fi, p.du, p.pixel00));
+    V3<T> org = p.center;
+    if (!(p.defocus_angle <= (T)0)) {
+        T px, py;
+        for (;;) {
+            px = RT_FMA((T)2, Real<T>::uniform(s), (T)-1);
+            py = RT_FMA((T)2, Real<T>::uniform(s), (T)-1);
+            if (RT_FMA(py, py, px * px) < (T)1) break;
+        }
+        org = madd3(py, p.ddv, madd3(px, p.ddu, p.center));
+    }
+    O = org;
+    D = {ps.x - org.x, ps.y - org.y, ps.z - org.z};
+    T inv = (T)1 / Real<T>::sqrt(dot3(D, D));
+    sky_uy = inv * D.y;
+}
+
+template <class T, int SRC>
+__global__ void __launch_bounds__(1024)
+render_kernel(const RenderParams<T> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* lds_geom = reinterpret_cast<T*>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int nthreads = blockDim.x;
+    if (SRC == RTIOW_SCENE_LDS) {
+        // Stage {cx,cy,cz,r^2} for all spheres: coalesced global reads, one pass.
+        for (int k = tid; k < p.n * 4; k += nthreads) lds_geom[k] = p.geom_a[k];
+        __syncthreads();
+    }
+
+    // lane -> pixel
+    int tx, ty;
+    if (p.wave_tiles) {
+        const int wave = tid >> 6, lane = tid & 63;
+        const int tiles_x = p.bx >> 3;
+        tx = (wave % tiles_x) * 8 + (lane & 7);
+        ty = (wave / tiles_x) * 8 + (lane >> 3);
+    } else {
+        tx = tid % p.bx;                        // CUDA's threadIdx.x
+        ty = tid / p.bx;                        // CUDA's threadIdx.y
+    }
+    const int i = blockIdx.x * p.bx + tx;
+    const int jl = blockIdx.y * p.by + ty;      // local row
+    if (i >= p.W || jl >= p.local_rows) return; // camera.h:133
+    const int j = ((jl / p.strip_rows) * p.nranks + p.rank) * p.strip_rows + (jl % p.strip_rows);
+    const size_t lp = (size_t)jl * p.W + i;
+    const size_t npix = (size_t)p.W * p.local_rows;
+
+    Rng rs;                                      // camera.h:136
+    rs.v0 = p.rng[0 * npix + lp]; rs.v1 = p.rng[1 * npix + lp]; rs.v2 = p.rng[2 * npix + lp];
+    rs.v3 = p.rng[3 * npix + lp]; rs.v4 = p.rng[4 * npix + lp]; rs.d = p.rng[5 * npix + lp];
+
+    V3<T> acc = {0, 0, 0};
+    const int S = p.S, B = p.B, N = p.n;
+
+    V3<T> O, D, atten;
+    T sky_uy;
+    int sample = 0, depth = 0;
+    if (S > 0) { gen_primary(p, i, j, rs, O, D, sky_uy); atten = {1, 1, 1}; }
+
+    while (sample < S) {
+        bool terminated;
+        V3<T> col = {0, 0, 0};
+        if (depth >= B) {
+            terminated = true;                   // camera.h:127 (also B <= 0)
+        } else {
+            // ---------------- hit_world (hittable.h:80-98), nearest (t, index) only
+            const T tmin = (T)0.001;
+            T closest = __builtin_huge_val();
+            int hit = -1;
+            const T a = dot3(D, D);              // hittable.h:43, ray-invariant
+            for (int s = 0; s < N; ++s) {
+                T cx, cy, cz, r2;
+                if (SRC == RTIOW_SCENE_LDS) {
+                    cx = lds_geom[4 * s + 0]; cy = lds_geom[4 * s + 1]; cz = lds_geom[4 * s + 2]; r2 = lds_geom[4 * s + 3];
+                } else {
+                    cx = p.geom_a[4 * s + 0]; cy = p.geom_a[4 * s + 1]; cz = p.geom_a[4 * s + 2]; r2 = p.geom_a[4 * s + 3];
+                }
+                const T ocx = cx - O.x, ocy = cy - O.y, ocz = cz - O.z;               // :42
+                const T h = RT_FMA(D.z, ocz, RT_FMA(D.y, ocy, D.x * ocx));          // :44
+                const T c = RT_FMA(ocz, ocz, RT_FMA(ocy, ocy, ocx * ocx)) - r2;     // :45
+                const T disc = RT_FMA(h, h, -(a * c));                              // :47
+                if (disc >= (T)0) {                                                 // :48
+                    const T sq = Real<T>::sqrt(disc);                               // :50
+                    T root = (h - sq) / a;                                          // :53
+                    bool ok = (tmin < root) && (root < closest);                    // :54
+                    if (!ok) {
+                        root = (h + sq) / a;                                        // :55
+                        ok = (tmin < root) && (root < closest);                     // :56
+                    }
+                    if (ok) { closest = root; hit = s; }                            // :88-92
+                }
+            }
+
+            if (hit < 0) {
+                // ------------ sky, from the PRIMARY ray (camera.h:120-124)
+                const double a_sky = 0.5 * ((double)sky_uy + 1.0);
+                const T w1 = (T)(1.0 - a_sky), w2 = (T)a_sky;
+                const V3<T> sky = {RT_FMA(w2, (T)0.5, w1), RT_FMA(w2, (T)0.7, w1), RT_FMA(w2, (T)1.0, w1)};
+                col = {atten.x * sky.x, atten.y * sky.y, atten.z * sky.z};
+                terminated = true;
+            } else {
+                // ------------ complete the hit record (hittable.h:59-63, :21-26)
+                const T* gb = p.geom_b + 4 * (size_t)hit;
+                const V3<T> C = {gb[0], gb[1], gb[2]};
+                const T inv_r = gb[3];
+                const V3<T> P = madd3(closest, D, O);
+                const V3<T> outward = {inv_r * (P.x - C.x), inv_r * (P.y - C.y), inv_r * (P.z - C.z)};
+                const bool front = dot3(D, outward) < (T)0;
+                const V3<T> nrm = front ? outward : V3<T>{-outward.x, -outward.y, -outward.z};
+                const int mtype = p.mat_type[hit];
+                const T* ma = p.mat_a + 4 * (size_t)hit;
+                V3<T> nd;
+                V3<T> att = {ma[0], ma[1], ma[2]};
+                bool ok = true;
+                if (mtype == RTIOW_DIELECTRIC) {                                     // material.h:68-89
+                    att = {1, 1, 1};
+                    const T* mb = p.mat_b + 2 * (size_t)hit;
+                    const T ri = front ? mb[1] : mb[0];
+                    const V3<T> ud = unit3(D);
+                    const T cos_theta = Real<T>::fmin(-dot3(ud, nrm), (T)1);
+                    const T sin_theta = Real<T>::sqrt(RT_FMA(-cos_theta, cos_theta, (T)1));
+                    bool reflect_it = ri * sin_theta > (T)1;
+                    if (!reflect_it) {
+                        T r0 = ((T)1 - ri) / ((T)1 + ri);                           // material.h:62-66
+                        r0 = r0 * r0;
+                        const float x = (float)((T)1 - cos_theta);
+                        const float x2 = x * x;
+                        const float p5 = (x2 * x2) * x;                              // powf(x,5), see DESIGN.md
+                        const T refl = RT_FMA((T)1 - r0, (T)p5, r0);
+                        reflect_it = refl > Real<T>::uniform(rs);
+                    }
+                    if (reflect_it) {
+                        nd = reflect3(ud, nrm);
+                    } else {                                                         // vec3.h:133-138
+                        const V3<T> perp = scale3(ri, madd3(cos_theta, nrm, ud));
+                        const T k = -Real<T>::sqrt(Real<T>::fabs((T)1 - dot3(perp, perp)));
+                        nd = madd3(k, nrm, perp);
+                    }
+                } else {
+                    const V3<T> ruv = random_unit_vector<T>(rs);
+                    if (mtype == RTIOW_LAMBERTIAN) {                                 // material.h:38-49
+                        nd = {nrm.x + ruv.x, nrm.y + ruv.y, nrm.z + ruv.z};
+                        const T e = Real<T>::near_zero;
+                        if (Real<T>::fabs(nd.x) < e && Real<T>::fabs(nd.y) < e && Real<T>::fabs(nd.z) < e) nd = nrm;
+                    } else {                                                         // material.h:51-59
+                        const V3<T> ur = unit3(reflect3(D, nrm));
+                        nd = madd3(ma[3], ruv, ur);
+                        ok = dot3(nd, nrm) > (T)0;
+                    }
+                }
+                if (ok) {                                                            // camera.h:110-115
+                    atten = {atten.x * att.x, atten.y * att.y, atten.z * att.z};
+                    O = P; D = nd;
+                    ++depth;
+                    terminated = false;
+                } else {
+                    terminated = true;                                               // camera.h:117
+                }
+            }
+        }
+        if (terminated) {
+            acc = {acc.x + col.x, acc.y + col.y, acc.z + col.z};                     // camera.h:160
+            ++sample;
+            depth = 0;
+            if (sample < S) { gen_primary(p, i, j, rs, O, D, sky_uy); atten = {1, 1, 1}; }
+        }
+    }
+
+    // camera.h:167-171, color.h:10-13.  RNG state is deliberately not written back.
+    acc = scale3(p.pixel_samples_scale, acc);
+    T* o = p.fb + lp * 3;
+    o[0] = acc.x > (T)0 ? Real<T>::sqrt(acc.x) : (T)0;
+    o[1] = acc.y > (T)0 ? Real<T>::sqrt(acc.y) : (T)0;
+    o[2] = acc.z > (T)0 ? Real<T>::sqrt(acc.z) : (T)0;
+}
+
+// Elementwise arithmetic probes (tests compare these with the host bit for bit).
+template <class T>
+__global__ void debug_ops_kernel(int op, size_t n, const T* a, const T* b, const T* c, T* out) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    switch (op) {
+        case 0: out[k] = a[k] / b[k]; break;
+        case 1: out[k] = Real<T>::sqrt(a[k]); break;
+        case 2: out[k] = Real<T>::fma(a[k], b[k], c[k]); break;
+        case 3: { uint32_t x; memcpy(&x, &a[k], 4); out[k] = Real<T>::from_u32(x); break; }
+        case 4: out[k] = a[k] * b[k] + c[k]; break;
+        default: out[k] = 0;
+    }
+}
+
+// =====================================================================================
+// host side of the library
+// =====================================================================================
+struct Mat160 { uint32_t col[XW_BITS][XW_WORDS]; };
+
+void mat_vec(const Mat160& m, const uint32_t* in, uint32_t* out) {
+    uint32_t acc[XW_WORDS] = {0, 0, 0, 0, 0};
+    for (int b = 0; b < XW_BITS; ++b)
+        if ((in[b >> 5] >> (b & 31)) & 1u)
+            for (int k = 0; k < XW_WORDS; ++k) acc[k] ^= m.col[b][k];
+    std::memcpy(out, acc, sizeof acc);
+}
+
+// Jump matrices A^(2^(67+b)), b = 0..31, of the xorshift part of XORWOW, by 67+31 squarings
+// of the one-step matrix (built by pushing the 160 basis vectors through the generator).
+std::vector<uint32_t> build_sequence_jump_matrices() {
+    Mat160 cur, nxt;
+    for (int b = 0; b < XW_BITS; ++b) {
+        uint32_t v[XW_WORDS] = {0, 0, 0, 0, 0};
+        v[b >> 5] = 1u << (b & 31);
+        const uint32_t t = v[0] ^ (v[0] >> 2);
+        const uint32_t n4 = (v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1));
+        cur.col[b][0] = v[1]; cur.col[b][1] = v[2]; cur.col[b][2] = v[3]; cur.col[b][3] = v[4]; cur.col[b][4] = n4;
+    }
+    std::vector<uint32_t> out;
+    out.reserve(XW_JUMPS * XW_MAT_WORDS);
+    for (int e = 0; e < 67 + XW_JUMPS; ++e) {
+        if (e >= 67) out.insert(out.end(), &cur.col[0][0], &cur.col[0][0] + XW_MAT_WORDS);
+        for (int b = 0; b < XW_BITS; ++b) mat_vec(cur, cur.col[b], nxt.col[b]);
+        cur = nxt;
+    }
+    return out;
+}
+
+}  // namespace
+
+struct rtiow_handle_s {
+    int device = 0;
+    int precision = 32;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+
+    // scene
+    int n = 0;
+    void *geom_a = nullptr, *geom_b = nullptr, *mat_a = nullptr, *mat_b = nullptr;
+    int* mat_type = nullptr;
+    // camera
+    bool have_camera = false;
+    rtiow_camera_f32 cam32{};
+    rtiow_camera_f64 cam64{};
+    // shard
+    int rank = 0, nranks = 1, strip_rows = 8;
+    int local_rows = 0;
+    // rng
+    uint32_t* rng = nullptr;
+    size_t rng_pixels = 0;
+    bool rng_ready = false;
+    uint32_t* jump = nullptr;
+    // framebuffer
+    void* fb = nullptr;
+    size_t fb_bytes = 0;
+    bool fb_external = false;
+    // knobs / stats
+    int scene_source = RTIOW_SCENE_LDS;
+    rtiow_stats stats{};
+};
+
+namespace {
+
+size_t elem_size(const rtiow_handle_s* h) { return h->precision == 64 ? 8 : 4; }
+
+int fail(rtiow_handle_s* h, hipError_t e, const char* file, int line) {
+    char buf[512];
+    // same text the reference's CUDA_SAFE_CALL prints (main.cu:16-17)
+    std::snprintf(buf, sizeof buf, "HIP_SAFE_CALL: %s %s %d", hipGetErrorString(e), file, line);
+    if (h) h->err = buf;
+    return (int)e;
+}
+int fail_arg(rtiow_handle_s* h, int code, const char* msg) { if (h) h->err = msg; return code; }
+
+#define HIP_TRY(h, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail((h), e_, __FILE__, __LINE__); } while (0)
+
+int compute_local_rows(int H, int rank, int nranks, int strip_rows) {
+    int rows = 0;
+    const int nstrips = (H + strip_rows - 1) / strip_rows;
+    for (int s = rank; s < nstrips; s += nranks) {
+        const int r0 = s * strip_rows;
+        rows += (r0 + strip_rows <= H) ? strip_rows : (H - r0);
+    }
+    return rows;
+}
+
+int img_w(const rtiow_handle_s* h) { return h->precision == 64 ? h->cam64.img_width : h->cam32.img_width; }
+int img_h(const rtiow_handle_s* h) { return h->precision == 64 ? h->cam64.img_height : h->cam32.img_height; }
+
+int ensure_framebuffer(rtiow_handle_s* h) {
+    const size_t need = (size_t)h->local_rows * img_w(h) * 3 * elem_size(h);
+    if (h->fb_external) {
+        if (h->fb_bytes < need) return fail_arg(h, RTIOW_E_BADARG, "bound framebuffer too small");
+        return 0;
+    }
+    if (h->fb && h->fb_bytes >= need) return 0;
+    if (h->fb) { HIP_TRY(h, hipFree(h->fb)); h->fb = nullptr; h->fb_bytes = 0; }
+    if (need == 0) return 0;
+    HIP_TRY(h, hipMalloc(&h->fb, need));
+    h->fb_bytes = need;
+    return 0;
+}
+
+template <class T, class CAM>
+RenderParams<T> make_params(const rtiow_handle_s* h, const CAM& c) {
+    RenderParams<T> p;
+    p.W = c.img_width; p.H = c.img_height; p.S = c.samples_per_pixel; p.B = c.max_depth;
+    p.pixel_samples_scale = c.pixel_samples_scale;
+    p.center = {c.center[0], c.center[1], c.center[2]};
+    p.pixel00 = {c.pixel00_loc[0], c.pixel00_loc[1], c.pixel00_loc[2]};
+    p.du = {c.pixel_delta_u[0], c.pixel_delta_u[1], c.pixel_delta_u[2]};
+    p.dv = {c.pixel_delta_v[0], c.pixel_delta_v[1], c.pixel_delta_v[2]};
+    p.defocus_angle = c.defocus_angle;
+    p.ddu = {c.defocus_disk_u[0], c.defocus_disk_u[1], c.defocus_disk_u[2]};
+    p.ddv = {c.defocus_disk_v[0], c.defocus_disk_v[1], c.defocus_disk_v[2]};
+    p.n = h->n;
+    p.geom_a = (const T*)h->geom_a; p.geom_b = (const T*)h->geom_b;
+    p.mat_a = (const T*)h->mat_a; p.mat_b = (const T*)h->mat_b; p.mat_type = h->mat_type;
+    p.rng = h->rng; p.fb = (T*)h->fb;
+    p.local_rows = h->local_rows; p.rank = h->rank; p.nranks = h->nranks; p.strip_rows = h->strip_rows;
+    return p;
+}
+
+template <class T>
+int upload_scene(rtiow_handle_s* h, int n, const T* cr, const T* af, const T* ri, const int32_t* type, const int32_t* valid) {
+    std::vector<T> ga, gb, ma, mb; std::vector<int> mt;
+    for (int i = 0; i < n; ++i) {
+        if (valid && !valid[i]) continue;
+        const T cx = cr[4 * i], cy = cr[4 * i + 1], cz = cr[4 * i + 2], r = cr[4 * i + 3];
+        if (type[i] < 0 || type[i] > 2) return fail_arg(h, RTIOW_E_BADARG, "material type out of range");
+        ga.insert(ga.end(), {cx, cy, cz, (T)(r * r)});          // hittable.h:45 radius*radius
+        gb.insert(gb.end(), {cx, cy, cz, (T)((T)1 / r)});       // vec3.h:89-91 (1/t)*v
+        ma.insert(ma.end(), {af[4 * i], af[4 * i + 1], af[4 * i + 2], af[4 * i + 3]});
+        mb.insert(mb.end(), {ri[i], (T)((T)1 / ri[i])});        // material.h:73 1.0f/refraction_index
+        mt.push_back(type[i]);
+    }
+    const int m = (int)mt.size();
+    if (m == 0) return fail_arg(h, RTIOW_E_BADARG, "scene has no valid spheres");
+    void** bufs[] = {&h->geom_a, &h->geom_b, &h->mat_a, &h->mat_b, (void**)&h->mat_type};
+    for (void** b : bufs) if (*b) { HIP_TRY(h, hipFree(*b)); *b = nullptr; }
+    HIP_TRY(h, hipMalloc(&h->geom_a, sizeof(T) * 4 * m));
+    HIP_TRY(h, hipMalloc(&h->geom_b, sizeof(T) * 4 * m));
+    HIP_TRY(h, hipMalloc(&h->mat_a, sizeof(T) * 4 * m));
+    HIP_TRY(h, hipMalloc(&h->mat_b, sizeof(T) * 2 * m));
+    HIP_TRY(h, hipMalloc((void**)&h->mat_type, sizeof(int) * m));
+    HIP_TRY(h, hipMemcpy(h->geom_a, ga.data(), sizeof(T) * 4 * m, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->geom_b, gb.data(), sizeof(T) * 4 * m, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->mat_a, ma.data(), sizeof(T) * 4 * m, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->mat_b, mb.data(), sizeof(T) * 2 * m, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->mat_type, mt.data(), sizeof(int) * m, hipMemcpyHostToDevice));
+    h->n = m;
+    h->stats.num_spheres = m;
+    return 0;
+}
+
+template <class T, class CAM>
+int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_tiles) {
+    RenderParams<T> p = make_params<T>(h, cam);
+    p.bx = bx; p.by = by; p.wave_tiles = wave_tiles;
+    dim3 grid((p.W + bx - 1) / bx, (h->local_rows + by - 1) / by);
+    dim3 block(bx * by);
+    const size_t lds = h->scene_source == RTIOW_SCENE_LDS ? sizeof(T) * 4 * (size_t)h->n : 0;
+    if (lds > 160 * 1024) return fail_arg(h, RTIOW_E_BADARG, "scene too large for LDS staging; use RTIOW_SCENE_SCALAR");
+    hipFuncAttributes fa{};
+    if (h->scene_source == RTIOW_SCENE_LDS) {
+        auto k = render_kernel<T, RTIOW_SCENE_LDS>;
+        if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipFuncGetAttributes(&fa, (const void*)k));
+        hipLaunchKernelGGL(k, grid, block, lds, h->stream, p);
+    } else {
+        auto k = render_kernel<T, RTIOW_SCENE_SCALAR>;
+        HIP_TRY(h, hipFuncGetAttributes(&fa, (const void*)k));
+        hipLaunchKernelGGL(k, grid, block, 0, h->stream, p);
+    }
+    HIP_TRY(h, hipGetLastError());
+    h->stats.vgprs = fa.numRegs;
+    h->stats.sgprs = 0;
+    h->stats.lds_bytes = (int)(lds + fa.sharedSizeBytes);
+    h->stats.block_x = bx; h->stats.block_y = by;
+    h->stats.scene_source = h->scene_source;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtiow_abi_version(void) { return RTIOW_ABI_VERSION; }
+
+int rtiow_create(int device, int precision, rtiow_handle* out) {
+    if (!out || (precision != 32 && precision != 64)) return RTIOW_E_BADARG;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess) return (int)e;
+    if (device < 0 || device >= count) return (int)hipErrorInvalidDevice;
+    rtiow_handle_s* h = new (std::nothrow) rtiow_handle_s();
+    if (!h) return RTIOW_E_NOMEM;
+    h->device = device; h->precision = precision;
+    if ((e = hipSetDevice(device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess) {
+        delete h;
+        return (int)e;
+    }
+    h->own_stream = true;
+    *out = h;
+    return 0;
+}
+
+int rtiow_destroy(rtiow_handle h) {
+    if (!h) return RTIOW_E_BADARG;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    void* bufs[] = {h->geom_a, h->geom_b, h->mat_a, h->mat_b, h->mat_type, h->rng, h->jump, h->fb_external ? nullptr : h->fb};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+const char* rtiow_last_error_string(rtiow_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int rtiow_set_stream(rtiow_handle h, void* hip_stream) {
+    if (!h) return RTIOW_E_BADARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->own_stream && h->stream) { HIP_TRY(h, hipStreamSynchronize(h->stream)); HIP_TRY(h, hipStreamDestroy(h->stream)); }
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+    return 0;
+}
+
+int rtiow_set_scene(rtiow_handle h, int n, const void* center_radius, const void* albedo_fuzz,
+                    const void* refraction_index, const int32_t* type, const int32_t* valid) {
+    if (!h) return RTIOW_E_BADARG;
+    if (n <= 0 || !center_radius || !albedo_fuzz || !refraction_index || !type) return fail_arg(h, RTIOW_E_BADARG, "rtiow_set_scene: null or empty table");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->precision == 32) return upload_scene<float>(h, n, (const float*)center_radius, (const float*)albedo_fuzz, (const float*)refraction_index, type, valid);
+    return upload_scene<double>(h, n, (const double*)center_radius, (const double*)albedo_fuzz, (const double*)refraction_index, type, valid);
+}
+
+int rtiow_set_camera(rtiow_handle h, const void* camera) {
+    if (!h || !camera) return RTIOW_E_BADARG;
+    int W, H, S;
+    if (h->precision == 32) { h->cam32 = *(const rtiow_camera_f32*)camera; W = h->cam32.img_width; H = h->cam32.img_height; S = h->cam32.samples_per_pixel; }
+    else { h->cam64 = *(const rtiow_camera_f64*)camera; W = h->cam64.img_width; H = h->cam64.img_height; S = h->cam64.samples_per_pixel; }
+    if (W <= 0 || H <= 0 || S < 0 || (int64_t)W * H > 0x7fffffffLL) { h->have_camera = false; return fail_arg(h, RTIOW_E_BADARG, "rtiow_set_camera: bad image size"); }
+    h->have_camera = true;
+    h->local_rows = compute_local_rows(H, h->rank, h->nranks, h->strip_rows);
+    h->stats.local_rows = h->local_rows;
+    h->rng_ready = false;
+    return 0;
+}
+
+int rtiow_set_shard(rtiow_handle h, int rank, int nranks, int strip_rows) {
+    if (!h) return RTIOW_E_BADARG;
+    if (nranks < 1 || rank < 0 || rank >= nranks || strip_rows < 1) return fail_arg(h, RTIOW_E_BADARG, "rtiow_set_shard: bad rank/nranks/strip_rows");
+    h->rank = rank; h->nranks = nranks; h->strip_rows = strip_rows;
+    if (h->have_camera) { h->local_rows = compute_local_rows(img_h(h), rank, nranks, strip_rows); h->stats.local_rows = h->local_rows; }
+    h->rng_ready = false;
+    return 0;
+}
+
+int rtiow_local_rows(rtiow_handle h, int* rows) {
+    if (!h || !rows) return RTIOW_E_BADARG;
+    if (!h->have_camera) return fail_arg(h, RTIOW_E_STATE, "rtiow_local_rows before rtiow_set_camera");
+    *rows = h->local_rows;
+    return 0;
+}
+
+int rtiow_local_row_map(rtiow_handle h, int32_t* rows_out) {
+    if (!h || !rows_out) return RTIOW_E_BADARG;
+    if (!h->have_camera) return fail_arg(h, RTIOW_E_STATE, "rtiow_local_row_map before rtiow_set_camera");
+    for (int jl = 0; jl < h->local_rows; ++jl)
+        rows_out[jl] = ((jl / h->strip_rows) * h->nranks + h->rank) * h->strip_rows + (jl % h->strip_rows);
+    return 0;
+}
+
+int rtiow_init_rng(rtiow_handle h, uint64_t seed) {
+    if (!h) return RTIOW_E_BADARG;
+    if (!h->have_camera) return fail_arg(h, RTIOW_E_STATE, "rtiow_init_rng before rtiow_set_camera");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->jump) {
+        std::vector<uint32_t> m = build_sequence_jump_matrices();
+        HIP_TRY(h, hipMalloc((void**)&h->jump, m.size() * sizeof(uint32_t)));
+        HIP_TRY(h, hipMemcpy(h->jump, m.data(), m.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    const int W = img_w(h), H = img_h(h);
+    const size_t npix = (size_t)W * h->local_rows;
+    if (h->rng_pixels < npix) {
+        if (h->rng) { HIP_TRY(h, hipFree(h->rng)); h->rng = nullptr; h->rng_pixels = 0; }
+        if (npix) HIP_TRY(h, hipMalloc((void**)&h->rng, npix * 6 * sizeof(uint32_t)));
+        h->rng_pixels = npix;
+    }
+    // cuRAND's published seed scrambling for curandStateXORWOW_t (curand_init).
+    const uint32_t x0 = (uint32_t)seed ^ 0xaad26b49u, x1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    const uint32_t t0 = 1099087573u * x0, t1 = 2591861531u * x1;
+    const uint32_t d0 = 6615241u + t1 + t0;
+    const uint32_t s0 = 123456789u + t0, s1 = 362436069u ^ t0, s2 = 521288629u + t1, s3 = 88675123u ^ t1, s4 = 5783321u + t0;
+    if (npix) {
+        HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+        const int threads = 256;
+        const unsigned blocks = (unsigned)((npix + threads - 1) / threads);
+        hipLaunchKernelGGL(rng_init_kernel, dim3(blocks), dim3(threads), 0, h->stream, h->rng, h->jump, d0, s0, s1, s2, s3, s4,
+                           W, H, h->local_rows, h->rank, h->nranks, h->strip_rows);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+        HIP_TRY(h, hipEventSynchronize(h->ev1));
+        float ms = 0;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        h->stats.rng_init_ms = ms;
+    }
+    h->rng_ready = true;
+    return 0;
+}
+
+int rtiow_render(rtiow_handle h, int threads_per_block_row, float* kernel_ms) {
+    if (!h) return RTIOW_E_BADARG;
+    if (!h->have_camera || h->n == 0) return fail_arg(h, RTIOW_E_STATE, "rtiow_render before rtiow_set_scene/rtiow_set_camera");
+    if (!h->rng_ready) return fail_arg(h, RTIOW_E_STATE, "rtiow_render before rtiow_init_rng");
+    const int T = threads_per_block_row;
+    if (T < 0 || T > 32) return fail_arg(h, RTIOW_E_BADARG, "rtiow_render: threads_per_block_row must be 0..32");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_framebuffer(h);
+    if (rc) return rc;
+    if (h->local_rows == 0) { if (kernel_ms) *kernel_ms = 0; return 0; }
+    int bx, by, wave_tiles;
+    if (T == 0) { bx = 16; by = 16; wave_tiles = 1; }       // library tiling: 4 waves, each an 8x8 tile
+    else if (T == 8) { bx = 8; by = 8; wave_tiles = 1; }    // == the reference's 8x8 block (one wave)
+    else { bx = T; by = T; wave_tiles = 0; }                 // the reference's T x T row-major block
+    if (kernel_ms) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));                     // main.cu:334
+    if (h->precision == 32) rc = launch_render<float>(h, h->cam32, bx, by, wave_tiles);
+    else rc = launch_render<double>(h, h->cam64, bx, by, wave_tiles);
+    if (rc) return rc;
+    const int S = h->precision == 32 ? h->cam32.samples_per_pixel : h->cam64.samples_per_pixel;
+    h->stats.primary_rays = (uint64_t)h->local_rows * img_w(h) * (uint64_t)S;
+    if (kernel_ms) {
+        HIP_TRY(h, hipEventRecord(h->ev1, h->stream));                                // main.cu:339
+        HIP_TRY(h, hipEventSynchronize(h->ev1));                                      // main.cu:337,340
+        float ms = 0;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        *kernel_ms = ms;
+        h->stats.render_ms = ms;
+    }
+    return 0;
+}
+
+int rtiow_bind_framebuffer(rtiow_handle h, void* device_ptr, size_t bytes) {
+    if (!h) return RTIOW_E_BADARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->fb_external && h->fb) { HIP_TRY(h, hipFree(h->fb)); }
+    h->fb = device_ptr; h->fb_bytes = device_ptr ? bytes : 0; h->fb_external = device_ptr != nullptr;
+    return 0;
+}
+
+int rtiow_framebuffer_device_ptr(rtiow_handle h, void** device_ptr, size_t* bytes) {
+    if (!h || !device_ptr) return RTIOW_E_BADARG;
+    if (!h->have_camera) return fail_arg(h, RTIOW_E_STATE, "framebuffer requested before rtiow_set_camera");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_framebuffer(h);
+    if (rc) return rc;
+    *device_ptr = h->fb;
+    if (bytes) *bytes = (size_t)h->local_rows * img_w(h) * 3 * elem_size(h);
+    return 0;
+}
+
+int rtiow_read_framebuffer(rtiow_handle h, void* host_rgb, size_t bytes) {
+    if (!h || !host_rgb) return RTIOW_E_BADARG;
+    if (!h->have_camera || !h->fb) return fail_arg(h, RTIOW_E_STATE, "rtiow_read_framebuffer before rtiow_render");
+    const size_t need = (size_t)h->local_rows * img_w(h) * 3 * elem_size(h);
+    if (bytes < need) return fail_arg(h, RTIOW_E_BADARG, "rtiow_read_framebuffer: host buffer too small");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(host_rgb, h->fb, need, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int rtiow_set_scene_source(rtiow_handle h, int scene_source) {
+    if (!h) return RTIOW_E_BADARG;
+    if (scene_source != RTIOW_SCENE_LDS && scene_source != RTIOW_SCENE_SCALAR) return fail_arg(h, RTIOW_E_BADARG, "unknown scene source");
+    h->scene_source = scene_source;
+    return 0;
+}
+
+int rtiow_get_stats(rtiow_handle h, rtiow_stats* out) {
+    if (!h || !out) return RTIOW_E_BADARG;
+    *out = h->stats;
+    return 0;
+}
+
+int rtiow_synchronize(rtiow_handle h) {
+    if (!h) return RTIOW_E_BADARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int rtiow_debug_read_rng(rtiow_handle h, uint32_t* host_states, size_t count_words) {
+    if (!h || !host_states) return RTIOW_E_BADARG;
+    if (!h->rng_ready) return fail_arg(h, RTIOW_E_STATE, "rtiow_debug_read_rng before rtiow_init_rng");
+    const size_t npix = (size_t)img_w(h) * h->local_rows;
+    if (count_words < npix * 6) return fail_arg(h, RTIOW_E_BADARG, "rtiow_debug_read_rng: buffer too small");
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::vector<uint32_t> soa(npix * 6);
+    HIP_TRY(h, hipMemcpy(soa.data(), h->rng, npix * 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < npix; ++p)
+        for (int k = 0; k < 6; ++k) host_states[p * 6 + k] = soa[k * npix + p];
+    return 0;
+}
+
+int rtiow_debug_ops(rtiow_handle h, int op, size_t n, const void* a, const void* b, const void* c, void* out) {
+    if (!h || !a || !out || n == 0) return RTIOW_E_BADARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t es = elem_size(h), bytes = n * es;
+    void *da = nullptr, *db = nullptr, *dc = nullptr, *dout = nullptr;
+    HIP_TRY(h, hipMalloc(&da, bytes)); HIP_TRY(h, hipMalloc(&db, bytes)); HIP_TRY(h, hipMalloc(&dc, bytes)); HIP_TRY(h, hipMalloc(&dout, bytes));
+    HIP_TRY(h, hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(db, b ? b : a, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(dc, c ? c : a, bytes, hipMemcpyHostToDevice));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (h->precision == 32) hipLaunchKernelGGL(debug_ops_kernel<float>, dim3(blocks), dim3(256), 0, h->stream, op, n, (const float*)da, (const float*)db, (const float*)dc, (float*)dout);
+    else hipLaunchKernelGGL(debug_ops_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, op, n, (const double*)da, (const double*)db, (const double*)dc, (double*)dout);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc); (void)hipFree(dout);
+    return 0;
+}
+
+}  // extern "C"
