@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the HIP render path.
+
+Metric (BASELINE.json): Mrays/s = W x H x samples / render time, on
+scene 3 (125 spheres, the reference's default: branch), 1920x1080, 100 spp, 50 bounces, fp32.
+One "step" = one full render of the frame (for N GPUs: every rank renders its interleaved
+row strips, then one RCCL gather of the strips to rank 0 -- the gather is inside the step).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline      dominant kernel (render) against the fp32 VALU peak: algorithmic flops per
+                launch = segments*(23*N+120) + rays*60 (segments counted on the
+                device by rtiow_count_segments) / mean HIP-event kernel time of the timed steps
+  cpu_baseline  the reference's serial tracer (oracle/_ref, built from the reference's own
+                sources) or, if absent, the oracle's serial port, timed on this host (1 thread)
+                on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+VALU_FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz
+VALU_FP64_PEAK_TFLOPS = 78.6
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene_id", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--samples", type=int, default=100)
+    ap.add_argument("--bounces", type=int, default=50)
+    ap.add_argument("--precision", type=int, default=32, choices=(32, 64))
+    ap.add_argument("--threads", type=int, default=0, help="reference --threads (block T x T); 0 = library tiling")
+    ap.add_argument("--scene_source", default="lds", choices=("lds", "scalar"))
+    ap.add_argument("--algorithm", default="direct", choices=("filtered", "direct"))
+    ap.add_argument("--strip_rows", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Reference serial tracer on a bounded sample: the same scene, camera, spp and bounces
+    on a 1/16-area frame (W/4 x H/4), 1 thread.  ~10-30 s of CPU work."""
+    W, H = max(args.width // 4, 16), max(args.height // 4, 9)
+    S, B = args.samples, args.bounces
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_serial_driver")
+    sample = "scene %d, %dx%d (the %dx%d view at 1/4 linear resolution), %d spp, depth %d, serial fp64" % (
+        args.scene_id, W, H, args.width, args.height, S, B)
+    rays = W * H * S
+    if os.path.exists(drv):
+        t0 = time.perf_counter()
+        r = subprocess.run([drv, str(args.scene_id), str(W), str(H), str(S), str(B)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        dt = time.perf_counter() - t0
+        if r.returncode == 0 and r.stdout.startswith(b"P3"):
+            return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
+                    "sample": sample + "; reference src/InOneWeekend headers built by oracle/Makefile", "seconds": dt}
+    from tests.oracle_lib import Oracle   # the oracle is only ever the checker / CPU baseline
+    orc = Oracle()
+    t0 = time.perf_counter()
+    orc.render_serial(args.scene_id, W, H, S, B)
+    dt = time.perf_counter() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": sample + "; oracle serial port", "seconds": dt}
+
+
+def pmc_traffic(args):
+    """HBM bytes per render launch from a committed rocprofv3 --pmc pass (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    key = "s%d_%dx%d_%dspp_%db_f%d" % (args.scene_id, args.width, args.height, args.samples, args.bounces, args.precision)
+    return json.load(open(path)).get(key, {}).get("hbm_bytes_per_launch")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import raytracingincuda_amd as rt
+    from raytracingincuda_amd.distributed import StripGather
+
+    prec = args.precision
+    tdtype = torch.float32 if prec == 32 else torch.float64
+    W, H, S, B = args.width, args.height, args.samples, args.bounces
+    scene = rt.build_scene(args.scene_id, prec)
+    cam = rt.camera(prec, W, H, S, B)
+
+    r = rt.Renderer(local_rank, prec)
+    stream = torch.cuda.current_stream()
+    r.set_stream(stream.cuda_stream)
+    r.set_camera(cam)
+    r.set_scene(scene)
+    r.set_scene_source(rt.SCENE_LDS if args.scene_source == "lds" else rt.SCENE_SCALAR)
+    r.set_algorithm(rt.ALGO_FILTERED if args.algorithm == "filtered" else rt.ALGO_DIRECT)
+    r.set_shard(rank, world, args.strip_rows)
+    gather = StripGather(W, H, rank, world, args.strip_rows, tdtype, "cuda:%d" % local_rank)
+    view = gather.local_view()
+    r.bind_framebuffer(view.data_ptr(), view.numel() * view.element_size())
+    r.init_rng(1227)                                   # untimed, like main.cu:326-330
+    segments = r.count_segments(args.threads)          # untimed; also a first warm launch
+    nspheres = r.stats()["num_spheres"]
+
+    def step(timed):
+        ms = r.render(args.threads, sync=timed)        # HIP events on the launch stream
+        if world > 1:
+            gather.gather()
+        return ms
+
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        kernel_ms.append(step(True))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed, float(np.mean(kernel_ms)), float(segments)], dtype=torch.float64, device="cuda")
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, kernel_mean_max, segments_total = float(tmax[0]), float(tmax[1]), float(tsum[2])
+    else:
+        kernel_mean_max, segments_total = float(np.mean(kernel_ms)), float(segments)
+
+    if rank == 0:
+        rays = float(W) * H * S
+        ms_per_step = elapsed / args.steps * 1e3
+        value = rays / (ms_per_step * 1e-3) / 1e6
+        # roofline of the dominant kernel (rank 0's launch; for N>1 this rank's shard)
+        my_rays = float(r.stats()["primary_rays"])
+        my_segments = float(segments)
+        flops = my_segments * (23.0 * nspheres + 120.0) + my_rays * 60.0
+        kms = float(np.mean(kernel_ms))
+        peak = VALU_FP32_PEAK_TFLOPS if prec == 32 else VALU_FP64_PEAK_TFLOPS
+        achieved = flops / (kms * 1e-3) / 1e12
+        fb_bytes = my_rays / S * 3 * (4 if prec == 32 else 8) + my_rays / S * 24
+        line = {
+            "metric": "Mrays/s (= W x H x samples / render time)",
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32" if prec == 32 else "f64", "data": "synthetic",
+            "config": {"workload": "scene %d (%d spheres), %dx%d, %d spp, %d bounces, XORWOW seed 1227" % (args.scene_id, nspheres, W, H, S, B),
+                       "scene_id": args.scene_id, "spheres": nspheres, "width": W, "height": H, "samples": S, "bounces": B,
+                       "threads": args.threads, "scene_source": args.scene_source, "hit_world": args.algorithm,
+                       "sharding": "interleaved %d-row strips, gather to rank 0 inside the step" % args.strip_rows if world > 1 else "none"},
+            "kernel_ms_mean": round(kms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
+            "kernel_ms_mean_max_over_ranks": round(kernel_mean_max, 4),
+            "segments_per_ray": round(segments_total / rays, 4),
+            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args),
+                         "algorithmic_flops_per_launch": flops, "algorithmic_hbm_bytes_per_launch": fb_bytes,
+                         "hbm_achieved_GBps": round(fb_bytes / (kms * 1e-3) / 1e9, 3), "hbm_peak_GBps": HBM_PEAK_GBS,
+                         "kernel": "render_kernel<%s>" % ("float" if prec == 32 else "double")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    r.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

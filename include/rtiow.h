@@ -41,6 +41,12 @@ extern "C" {
 #define RTIOW_SCENE_LDS    0    /* sphere list staged into LDS per workgroup (default) */
 #define RTIOW_SCENE_SCALAR 1    /* wave-uniform scalar loads through the scalar cache  */
 
+/* hit_world strategy (both give the same image bit for bit):
+ * DIRECT   = the reference loop (hittable.h:80-98): every sphere tested exactly (default);
+ * FILTERED = conservative per-sphere filter + exact test of the surviving candidates. */
+#define RTIOW_ALGO_DIRECT   0
+#define RTIOW_ALGO_FILTERED 1
+
 typedef struct rtiow_handle_s* rtiow_handle;
 
 /* The fields of `struct camera` that `render` reads (camera.h:10-30), produced by
@@ -72,6 +78,7 @@ typedef struct {
     int32_t  vgprs, sgprs;       /* register use of the render kernel variant (0: unknown) */
     int32_t  lds_bytes;          /* dynamic+static LDS per workgroup of the last render    */
     int32_t  scene_source;       /* RTIOW_SCENE_*                                          */
+    int32_t  algorithm;          /* RTIOW_ALGO_*                                           */
 } rtiow_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------
@@ -116,6 +123,11 @@ int rtiow_init_rng(rtiow_handle h, uint64_t seed);
  * makes the call asynchronous on the handle's stream. */
 int rtiow_render(rtiow_handle h, int threads_per_block_row, float* kernel_ms);
 
+/* Same render with a path-segment counter (hit_world calls, hittable.h:80) added: untimed,
+ * used by bench.py for the algorithmic-flop figure and by tests against the oracle's count.
+ * The image it leaves in the framebuffer is identical to rtiow_render's. */
+int rtiow_count_segments(rtiow_handle h, int threads_per_block_row, uint64_t* segments);
+
 /* Framebuffer: `vec3 pixel_buffer[]` (main.cu:133-134), local_rows x width x 3 T, row-major.
  * By default device memory owned by the library; rtiow_bind_framebuffer lets the caller
  * supply device memory (e.g. a torch tensor that torch.distributed will gather). */
@@ -126,6 +138,7 @@ int rtiow_read_framebuffer(rtiow_handle h, void* host_rgb, size_t bytes);
 
 /* ---- knobs / introspection */
 int rtiow_set_scene_source(rtiow_handle h, int scene_source /* RTIOW_SCENE_* */);
+int rtiow_set_algorithm(rtiow_handle h, int algorithm /* RTIOW_ALGO_* */);
 int rtiow_get_stats(rtiow_handle h, rtiow_stats* out);
 int rtiow_synchronize(rtiow_handle h);
 

@@ -45,6 +45,11 @@ int rtiow_host_ppm_filename(int precision, int scene_id, int width, int height, 
 int rtiow_host_write_ppm(const char* path, int precision, int width, int height, const void* rgb);
 int rtiow_host_format_ppm(int precision, int width, int height, const void* rgb, char* out, size_t cap, size_t* len);
 
+/* Row sharding used by rtiow_set_shard (rtiow.h): strips of strip_rows rows dealt round-robin.
+ * Writes the global row index of every local row of `rank` (rows_out may be NULL) and returns
+ * the local row count (negative on bad arguments). */
+int rtiow_host_shard_rows(int height, int rank, int nranks, int strip_rows, int32_t* rows_out);
+
 /* Scatter `local_rows` rows rendered by shard (rank, nranks, strip_rows) into the full
  * image (both width*rows*3 T).  Used after the gather in multi-GPU runs. */
 int rtiow_host_place_rows(int precision, int width, int height, int rank, int nranks, int strip_rows,

@@ -22,6 +22,7 @@ import numpy as np
 
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 SCENE_LDS, SCENE_SCALAR = 0, 1
+ALGO_DIRECT, ALGO_FILTERED = 0, 1
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIBDIR = os.path.join(_PKG, "lib")
@@ -58,20 +59,20 @@ class Stats(ctypes.Structure):
                 ("primary_rays", ctypes.c_uint64), ("local_rows", ctypes.c_int32),
                 ("num_spheres", ctypes.c_int32), ("block_x", ctypes.c_int32), ("block_y", ctypes.c_int32),
                 ("vgprs", ctypes.c_int32), ("sgprs", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
-                ("scene_source", ctypes.c_int32)]
+                ("scene_source", ctypes.c_int32), ("algorithm", ctypes.c_int32)]
 
 
 # Every symbol include/rtiow.h declares (tests check that the built library exports them all).
 HIP_SYMBOLS = [
     "rtiow_abi_version", "rtiow_create", "rtiow_destroy", "rtiow_last_error_string", "rtiow_set_stream",
     "rtiow_set_scene", "rtiow_set_camera", "rtiow_set_shard", "rtiow_local_rows", "rtiow_local_row_map",
-    "rtiow_init_rng", "rtiow_render", "rtiow_bind_framebuffer", "rtiow_framebuffer_device_ptr",
-    "rtiow_read_framebuffer", "rtiow_set_scene_source", "rtiow_get_stats", "rtiow_synchronize",
+    "rtiow_init_rng", "rtiow_render", "rtiow_count_segments", "rtiow_bind_framebuffer", "rtiow_framebuffer_device_ptr",
+    "rtiow_read_framebuffer", "rtiow_set_scene_source", "rtiow_set_algorithm", "rtiow_get_stats", "rtiow_synchronize",
     "rtiow_debug_read_rng", "rtiow_debug_ops",
 ]
 HOST_SYMBOLS = [
     "rtiow_host_scene_slots", "rtiow_host_build_scene", "rtiow_host_camera", "rtiow_host_ppm_filename",
-    "rtiow_host_write_ppm", "rtiow_host_format_ppm", "rtiow_host_place_rows",
+    "rtiow_host_write_ppm", "rtiow_host_format_ppm", "rtiow_host_shard_rows", "rtiow_host_place_rows",
 ]
 
 _hip = None
@@ -97,6 +98,7 @@ def load_host_library():
         lib.rtiow_host_write_ppm.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
         lib.rtiow_host_format_ppm.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_char_p,
                                               ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        lib.rtiow_host_shard_rows.argtypes = [ctypes.c_int] * 4 + [i32p]
         lib.rtiow_host_place_rows.argtypes = [ctypes.c_int] * 6 + [vp, vp]
         _host = lib
     return _host
@@ -125,10 +127,12 @@ def load_hip_library():
         lib.rtiow_local_row_map.argtypes = [H, i32p]
         lib.rtiow_init_rng.argtypes = [H, ctypes.c_uint64]
         lib.rtiow_render.argtypes = [H, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+        lib.rtiow_count_segments.argtypes = [H, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
         lib.rtiow_bind_framebuffer.argtypes = [H, vp, ctypes.c_size_t]
         lib.rtiow_framebuffer_device_ptr.argtypes = [H, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
         lib.rtiow_read_framebuffer.argtypes = [H, vp, ctypes.c_size_t]
         lib.rtiow_set_scene_source.argtypes = [H, ctypes.c_int]
+        lib.rtiow_set_algorithm.argtypes = [H, ctypes.c_int]
         lib.rtiow_get_stats.argtypes = [H, ctypes.POINTER(Stats)]
         lib.rtiow_synchronize.argtypes = [H]
         lib.rtiow_debug_read_rng.argtypes = [H, ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t]
@@ -226,6 +230,18 @@ def write_ppm(path, rgb):
         raise RtiowError(rc, "Could not open file for writing: %s" % path)
 
 
+def shard_rows(height, rank, nranks, strip_rows=8):
+    """Global row indices rendered by `rank` (same rule as rtiow_set_shard)."""
+    lib = load_host_library()
+    n = lib.rtiow_host_shard_rows(height, rank, nranks, strip_rows, None)
+    if n < 0:
+        raise RtiowError(n, "rtiow_host_shard_rows: bad arguments")
+    rows = np.zeros(n, np.int32)
+    if n:
+        lib.rtiow_host_shard_rows(height, rank, nranks, strip_rows, rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    return rows
+
+
 def place_rows(full_rgb, local_rgb, rank, nranks, strip_rows):
     """Scatter one shard's rows (rtiow_set_shard order) into the full [H, W, 3] image."""
     assert full_rgb.flags.c_contiguous and local_rgb.flags.c_contiguous and full_rgb.dtype == local_rgb.dtype
@@ -298,6 +314,9 @@ class Renderer:
     def set_scene_source(self, source):
         self._check(self._lib.rtiow_set_scene_source(self._h, source))
 
+    def set_algorithm(self, algorithm):
+        self._check(self._lib.rtiow_set_algorithm(self._h, algorithm))
+
     @property
     def local_rows(self):
         n = ctypes.c_int(0)
@@ -321,6 +340,12 @@ class Renderer:
             return ms.value
         self._check(self._lib.rtiow_render(self._h, int(threads), None))
         return None
+
+    def count_segments(self, threads=8):
+        """Untimed render that also counts path segments (hit_world calls)."""
+        n = ctypes.c_uint64(0)
+        self._check(self._lib.rtiow_count_segments(self._h, int(threads), ctypes.byref(n)))
+        return n.value
 
     def bind_framebuffer(self, device_ptr, nbytes):
         self._check(self._lib.rtiow_bind_framebuffer(self._h, ctypes.c_void_p(int(device_ptr)), nbytes))

@@ -82,6 +82,15 @@ def build(force=False, verbose=True):
             path = os.path.join(tools, src)
             if force or _newer(exe, [path, me]):
                 _run(["g++", "-O2", "-std=c++17", "-o", exe, path], verbose)
+    gpu_tools = os.path.join(CSRC, "tools_gpu")
+    if os.path.isdir(gpu_tools):
+        for src in sorted(os.listdir(gpu_tools)):
+            if not src.endswith(".hip"):
+                continue
+            exe = os.path.join(BIN, src[:-4])
+            path = os.path.join(gpu_tools, src)
+            if force or _newer(exe, [path, me]):
+                _run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-o", exe, path], verbose)
     return {"hip": hip_so, "host": host_so, "bin": BIN}
 
 

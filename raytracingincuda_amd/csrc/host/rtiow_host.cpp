@@ -232,6 +232,16 @@ int rtiow_host_write_ppm(const char* path, int precision, int width, int height,
     return (std::fclose(f) == 0 && ok) ? 0 : RTIOW_E_STATE;
 }
 
+int rtiow_host_shard_rows(int height, int rank, int nranks, int strip_rows, int32_t* rows_out) {
+    if (height <= 0 || nranks < 1 || rank < 0 || rank >= nranks || strip_rows < 1) return RTIOW_E_BADARG;
+    const int nstrips = (height + strip_rows - 1) / strip_rows;
+    int n = 0;
+    for (int s = rank; s < nstrips; s += nranks)
+        for (int r = s * strip_rows; r < (s + 1) * strip_rows && r < height; ++r, ++n)
+            if (rows_out) rows_out[n] = r;
+    return n;
+}
+
 int rtiow_host_place_rows(int precision, int width, int height, int rank, int nranks, int strip_rows,
                           const void* local_rgb, void* full_rgb) {
     if (!local_rgb || !full_rgb || width <= 0 || height <= 0 || nranks < 1 || rank < 0 || rank >= nranks || strip_rows < 1) return RTIOW_E_BADARG;

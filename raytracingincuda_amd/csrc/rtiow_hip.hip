@@ -63,6 +63,7 @@ template <> struct Real<float> {
     static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
     static __device__ __forceinline__ float sqrt(float a) { return __builtin_sqrtf(a); }
     static __device__ __forceinline__ float fmin(float a, float b) { return __builtin_fminf(a, b); }
+    static __device__ __forceinline__ float fmax(float a, float b) { return __builtin_fmaxf(a, b); }
     static __device__ __forceinline__ float fabs(float a) { return __builtin_fabsf(a); }
     static constexpr float near_zero = 1e-6f;   // vec3.h:50
     static constexpr float ruv_eps = 1e-8f;     // vec3.h:124
@@ -81,6 +82,7 @@ template <> struct Real<double> {
     static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
     static __device__ __forceinline__ double sqrt(double a) { return __builtin_sqrt(a); }
     static __device__ __forceinline__ double fmin(double a, double b) { return __builtin_fmin(a, b); }
+    static __device__ __forceinline__ double fmax(double a, double b) { return __builtin_fmax(a, b); }
     static __device__ __forceinline__ double fabs(double a) { return __builtin_fabs(a); }
     static constexpr double near_zero = 1e-8;   // GlobalDouble vec3.h:50
     static constexpr double ruv_eps = 1e-160;   // GlobalDouble vec3.h:125
@@ -141,8 +143,8 @@ template <class T> struct RenderParams {
     V3<T> center, pixel00, du, dv;
     T defocus_angle;
     V3<T> ddu, ddv;
-    int n;
-    const T* __restrict__ geom_a;     // [n][4] cx,cy,cz,r*r       (sphere loop)
+    int n, n_padded;                  // spheres, and the table length padded to a multiple of 4
+    const T* __restrict__ geom_a;     // [n_padded][4] cx,cy,cz,r*r (sphere loop; padding never hits)
     const T* __restrict__ geom_b;     // [n][4] cx,cy,cz,1/r       (hit completion)
     const T* __restrict__ mat_a;      // [n][4] albedo rgb, fuzz
     const T* __restrict__ mat_b;      // [n][2] ri, 1/ri
@@ -152,6 +154,7 @@ template <class T> struct RenderParams {
     int local_rows, rank, nranks, strip_rows;
     int bx, by;                       // tile (block) shape in pixels
     int wave_tiles;                   // 1: lanes of a wave form 8x8 tiles inside the block
+    unsigned long long* seg_counter;  // COUNT variant only: total hit_world calls (path segments)
 };
 
 #define RT_FMA(a, b, c) Real<T>::fma((a), (b), (c))
@@ -210,7 +213,146 @@ __device__ __forceinline__ void gen_primary(const RenderParams<T>& p, int i, int
     sky_uy = inv * D.y;
 }
 
+// ---- raw hardware square root (v_sqrt_f32 / v_sqrt_f64): ~1 ulp / ~2^-23 relative.  Used ONLY
+// by the conservative candidate filter below, never for a value that reaches the image.
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double fast_sqrt(double x) { return __builtin_amdgcn_sqrt(x); }
+
 template <class T, int SRC>
+__device__ __forceinline__ void load_sphere(const RenderParams<T>& p, const T* lds_geom, int s, T& cx, T& cy, T& cz, T& r2) {
+    const T* g = (SRC == RTIOW_SCENE_LDS) ? lds_geom : p.geom_a;
+    cx = g[4 * s + 0]; cy = g[4 * s + 1]; cz = g[4 * s + 2]; r2 = g[4 * s + 3];
+}
+
+// hit_sphere (hittable.h:40-57) for sphere `s` against the running (closest, hit) pair,
+// exactly as the reference evaluates it (IEEE sqrt and divisions).
+template <class T, int SRC>
+__device__ __forceinline__ void exact_sphere_test(const RenderParams<T>& p, const T* lds_geom, int s, V3<T> O, V3<T> D, T a,
+                                                  T& closest, int& hit) {
+    T cx, cy, cz, r2;
+    load_sphere<T, SRC>(p, lds_geom, s, cx, cy, cz, r2);
+    const T tmin = (T)0.001;
+    const T ocx = cx - O.x, ocy = cy - O.y, ocz = cz - O.z;               // :42
+    const T h = RT_FMA(D.z, ocz, RT_FMA(D.y, ocy, D.x * ocx));          // :44
+    const T c = RT_FMA(ocz, ocz, RT_FMA(ocy, ocy, ocx * ocx)) - r2;     // :45
+    const T disc = RT_FMA(h, h, -(a * c));                              // :47
+    if (disc >= (T)0) {                                                 // :48
+        const T sq = Real<T>::sqrt(disc);                               // :50
+        T root = (h - sq) / a;                                          // :53
+        bool ok = (tmin < root) && (root < closest);                    // :54
+        if (!ok) {
+            root = (h + sq) / a;                                        // :55
+            ok = (tmin < root) && (root < closest);                     // :56
+        }
+        if (ok) { closest = root; hit = s; }                            // hittable.h:88-92
+    }
+}
+
+// Second half of hit_sphere (hittable.h:50-57) once the discriminant is known to be >= 0.
+template <class T>
+__device__ __forceinline__ void finish_sphere_test(int s, T h, T disc, T a, T& closest, int& hit) {
+    const T tmin = (T)0.001;
+    const T sq = Real<T>::sqrt(disc);                               // :50
+    T root = (h - sq) / a;                                          // :53
+    bool ok = (tmin < root) && (root < closest);                    // :54
+    if (!ok) {
+        root = (h + sq) / a;                                        // :55
+        ok = (tmin < root) && (root < closest);                     // :56
+    }
+    if (ok) { closest = root; hit = s; }                            // hittable.h:88-92
+}
+
+// hit_world (hittable.h:80-98), ALGO 0: every sphere tested exactly, in index order.
+// The table is padded to a multiple of 4 with never-hit entries (r^2 = -1e12 => disc < 0), so
+// the loop runs 4 spheres per trip: 4 x 12 VALU for the discriminants (hittable.h:42-47),
+// ONE wave-level branch on max(disc0..3) >= 0 (a lane rarely reaches a sphere's line, ~4 % of
+// the trips for the reference scenes), and the IEEE sqrt/divide tail only inside it.
+template <class T, int SRC>
+__device__ __forceinline__ void hit_world_direct(const RenderParams<T>& p, const T* lds_geom, V3<T> O, V3<T> D, T a,
+                                                 T& closest, int& hit) {
+    const T* g = (SRC == RTIOW_SCENE_LDS) ? lds_geom : p.geom_a;
+    for (int s = 0; s < p.n_padded; s += 4) {
+        T h[4], disc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const T cx = g[4 * (s + k) + 0], cy = g[4 * (s + k) + 1], cz = g[4 * (s + k) + 2], r2 = g[4 * (s + k) + 3];
+            const T ocx = cx - O.x, ocy = cy - O.y, ocz = cz - O.z;               // :42
+            h[k] = RT_FMA(D.z, ocz, RT_FMA(D.y, ocy, D.x * ocx));                 // :44
+            const T c = RT_FMA(ocz, ocz, RT_FMA(ocy, ocy, ocx * ocx)) - r2;       // :45
+            disc[k] = RT_FMA(h[k], h[k], -(a * c));                               // :47
+        }
+        const T m = Real<T>::fmax(Real<T>::fmax(disc[0], disc[1]), Real<T>::fmax(disc[2], disc[3]));
+        if (m >= (T)0) {                                                          // :48 for any of the four
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (disc[k] >= (T)0) finish_sphere_test<T>(s + k, h[k], disc[k], a, closest, hit);
+        }
+    }
+}
+
+// hit_world, ALGO 1: same result bit for bit, two phases.
+//  Phase 1 walks all spheres with the reference's own discriminant arithmetic and DROPS a
+//  sphere only when it provably cannot change (closest, hit) in the exact loop:
+//    (behind)  h <= 0 and a*c > 0  =>  sqrt(disc) <= |h| in IEEE arithmetic, both roots <= 0 < tmin;
+//    (far)     a lower bound of its near-root numerator h - sqrt(disc) exceeds an upper bound
+//              `ub` of the numerator of a root the exact loop has provably accepted earlier
+//              (all roots of one ray share the divisor a > 0, so numerators order like roots).
+//  The bounds use the raw v_sqrt (error <= 2^-22 relative) inside a 2^-20 guard band, so a
+//  sphere whose status is in doubt is always kept.  Survivors go to a 4-entry per-lane queue.
+//  Phase 2 drains the queue in index order through exact_sphere_test: the dropped spheres
+//  are no-ops of the exact loop, so (closest, hit) is what hit_world_direct returns.
+//  The IEEE sqrt + 2 divisions (~45 instructions) thus run once per queue slot per wave
+//  instead of once per sphere per wave.  DESIGN.md §"Candidate filter" has the proofs.
+template <class T, int SRC>
+__device__ __forceinline__ void hit_world_filtered(const RenderParams<T>& p, const T* lds_geom, V3<T> O, V3<T> D, T a,
+                                                   T& closest, int& hit) {
+    const T kappa = (T)9.5367431640625e-07;                 // 2^-20 guard band
+    const T tmin_hi = ((T)0.001 * a) * (T)1.00000095367431640625;   // tmin*a*(1+2^-20): "near root provably > tmin"
+    T ub = __builtin_huge_val();                            // numerator bound of a provably accepted root
+    unsigned q_lo = 0xffffffffu, q_hi = 0xffffffffu;        // 4 x 16-bit sphere indices, 0xffff = empty
+
+    auto drain = [&]() {
+#pragma unroll
+        for (int slot = 3; slot >= 0; --slot) {             // oldest entry first = index order
+            const unsigned e = ((slot >= 2 ? q_hi : q_lo) >> ((slot & 1) * 16)) & 0xffffu;
+            if (e != 0xffffu) exact_sphere_test<T, SRC>(p, lds_geom, (int)e, O, D, a, closest, hit);
+        }
+        q_lo = q_hi = 0xffffffffu;
+        if (hit >= 0) {                                      // exact closest tightens the bound
+            const T cb = (closest * a) * (T)1.00000095367431640625;
+            ub = cb < ub ? cb : ub;
+        }
+    };
+
+    for (int s = 0; s < p.n; ++s) {
+        T cx, cy, cz, r2;
+        load_sphere<T, SRC>(p, lds_geom, s, cx, cy, cz, r2);
+        const T ocx = cx - O.x, ocy = cy - O.y, ocz = cz - O.z;
+        const T h = RT_FMA(D.z, ocz, RT_FMA(D.y, ocy, D.x * ocx));
+        const T c = RT_FMA(ocz, ocz, RT_FMA(ocy, ocy, ocx * ocx)) - r2;
+        const T nac = -(a * c);
+        const T disc = RT_FMA(h, h, nac);
+        // keep unless (disc < 0) or (behind: h <= 0 and a*c > 0); NaNs are kept
+        const T in_front = Real<T>::fmin(disc, h);
+        const T keep = in_front > nac ? in_front : nac;
+        if (!(keep < (T)0)) {
+            const T sq = fast_sqrt(disc);
+            const T e = RT_FMA(kappa, Real<T>::fabs(h) + sq, (T)1e-30);
+            const T n1 = h - sq;
+            const T n1_lo = n1 - e;
+            if (!(n1_lo > ub)) {                             // not provably farther: enqueue
+                q_hi = __builtin_amdgcn_alignbit(q_hi, q_lo, 16);
+                q_lo = (q_lo << 16) | (unsigned)s;
+                const T n1_hi = (n1 + e) * (T)1.00000095367431640625;
+                if (n1_lo > tmin_hi) ub = n1_hi < ub ? n1_hi : ub;
+                if (__builtin_amdgcn_ballot_w64(q_hi < 0xffff0000u) != 0) drain();   // some lane's queue is full
+            }
+        }
+    }
+    drain();
+}
+
+template <class T, int SRC, bool COUNT, int ALGO>
 __global__ void __launch_bounds__(1024)
 render_kernel(const RenderParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -220,7 +362,7 @@ render_kernel(const RenderParams<T> p) {
     const int nthreads = blockDim.x;
     if (SRC == RTIOW_SCENE_LDS) {
         // Stage {cx,cy,cz,r^2} for all spheres: coalesced global reads, one pass.
-        for (int k = tid; k < p.n * 4; k += nthreads) lds_geom[k] = p.geom_a[k];
+        for (int k = tid; k < p.n_padded * 4; k += nthreads) lds_geom[k] = p.geom_a[k];
         __syncthreads();
     }
 
@@ -247,11 +389,12 @@ render_kernel(const RenderParams<T> p) {
     rs.v3 = p.rng[3 * npix + lp]; rs.v4 = p.rng[4 * npix + lp]; rs.d = p.rng[5 * npix + lp];
 
     V3<T> acc = {0, 0, 0};
-    const int S = p.S, B = p.B, N = p.n;
+    const int S = p.S, B = p.B;
 
     V3<T> O, D, atten;
     T sky_uy;
     int sample = 0, depth = 0;
+    unsigned int nseg = 0;
     if (S > 0) { gen_primary(p, i, j, rs, O, D, sky_uy); atten = {1, 1, 1}; }
 
     while (sample < S) {
@@ -261,32 +404,12 @@ render_kernel(const RenderParams<T> p) {
             terminated = true;                   // camera.h:127 (also B <= 0)
         } else {
             // ---------------- hit_world (hittable.h:80-98), nearest (t, index) only
-            const T tmin = (T)0.001;
             T closest = __builtin_huge_val();
             int hit = -1;
             const T a = dot3(D, D);              // hittable.h:43, ray-invariant
-            for (int s = 0; s < N; ++s) {
-                T cx, cy, cz, r2;
-                if (SRC == RTIOW_SCENE_LDS) {
-                    cx = lds_geom[4 * s + 0]; cy = lds_geom[4 * s + 1]; cz = lds_geom[4 * s + 2]; r2 = lds_geom[4 * s + 3];
-                } else {
-                    cx = p.geom_a[4 * s + 0]; cy = p.geom_a[4 * s + 1]; cz = p.geom_a[4 * s + 2]; r2 = p.geom_a[4 * s + 3];
-                }
-                const T ocx = cx - O.x, ocy = cy - O.y, ocz = cz - O.z;               // :42
-                const T h = RT_FMA(D.z, ocz, RT_FMA(D.y, ocy, D.x * ocx));          // :44
-                const T c = RT_FMA(ocz, ocz, RT_FMA(ocy, ocy, ocx * ocx)) - r2;     // :45
-                const T disc = RT_FMA(h, h, -(a * c));                              // :47
-                if (disc >= (T)0) {                                                 // :48
-                    const T sq = Real<T>::sqrt(disc);                               // :50
-                    T root = (h - sq) / a;                                          // :53
-                    bool ok = (tmin < root) && (root < closest);                    // :54
-                    if (!ok) {
-                        root = (h + sq) / a;                                        // :55
-                        ok = (tmin < root) && (root < closest);                     // :56
-                    }
-                    if (ok) { closest = root; hit = s; }                            // :88-92
-                }
-            }
+            if (COUNT) ++nseg;
+            if (ALGO == 0) hit_world_direct<T, SRC>(p, lds_geom, O, D, a, closest, hit);
+            else hit_world_filtered<T, SRC>(p, lds_geom, O, D, a, closest, hit);
 
             if (hit < 0) {
                 // ------------ sky, from the PRIMARY ray (camera.h:120-124)
@@ -363,6 +486,7 @@ render_kernel(const RenderParams<T> p) {
         }
     }
 
+    if (COUNT) atomicAdd(p.seg_counter, (unsigned long long)nseg);
     // camera.h:167-171, color.h:10-13.  RNG state is deliberately not written back.
     acc = scale3(p.pixel_samples_scale, acc);
     T* o = p.fb + lp * 3;
@@ -431,7 +555,7 @@ struct rtiow_handle_s {
     std::string err;
 
     // scene
-    int n = 0;
+    int n = 0, n_padded = 0;
     void *geom_a = nullptr, *geom_b = nullptr, *mat_a = nullptr, *mat_b = nullptr;
     int* mat_type = nullptr;
     // camera
@@ -452,6 +576,7 @@ struct rtiow_handle_s {
     bool fb_external = false;
     // knobs / stats
     int scene_source = RTIOW_SCENE_LDS;
+    int algorithm = RTIOW_ALGO_DIRECT;
     rtiow_stats stats{};
 };
 
@@ -509,7 +634,7 @@ RenderParams<T> make_params(const rtiow_handle_s* h, const CAM& c) {
     p.defocus_angle = c.defocus_angle;
     p.ddu = {c.defocus_disk_u[0], c.defocus_disk_u[1], c.defocus_disk_u[2]};
     p.ddv = {c.defocus_disk_v[0], c.defocus_disk_v[1], c.defocus_disk_v[2]};
-    p.n = h->n;
+    p.n = h->n; p.n_padded = h->n_padded;
     p.geom_a = (const T*)h->geom_a; p.geom_b = (const T*)h->geom_b;
     p.mat_a = (const T*)h->mat_a; p.mat_b = (const T*)h->mat_b; p.mat_type = h->mat_type;
     p.rng = h->rng; p.fb = (T*)h->fb;
@@ -532,41 +657,50 @@ int upload_scene(rtiow_handle_s* h, int n, const T* cr, const T* af, const T* ri
     }
     const int m = (int)mt.size();
     if (m == 0) return fail_arg(h, RTIOW_E_BADARG, "scene has no valid spheres");
+    const int mp = (m + 3) / 4 * 4;
+    for (int i = m; i < mp; ++i) ga.insert(ga.end(), {(T)0, (T)0, (T)0, (T)-1e12});   // c = |oc|^2 + 1e12 => disc < 0: never hit
     void** bufs[] = {&h->geom_a, &h->geom_b, &h->mat_a, &h->mat_b, (void**)&h->mat_type};
     for (void** b : bufs) if (*b) { HIP_TRY(h, hipFree(*b)); *b = nullptr; }
-    HIP_TRY(h, hipMalloc(&h->geom_a, sizeof(T) * 4 * m));
+    HIP_TRY(h, hipMalloc(&h->geom_a, sizeof(T) * 4 * mp));
     HIP_TRY(h, hipMalloc(&h->geom_b, sizeof(T) * 4 * m));
     HIP_TRY(h, hipMalloc(&h->mat_a, sizeof(T) * 4 * m));
     HIP_TRY(h, hipMalloc(&h->mat_b, sizeof(T) * 2 * m));
     HIP_TRY(h, hipMalloc((void**)&h->mat_type, sizeof(int) * m));
-    HIP_TRY(h, hipMemcpy(h->geom_a, ga.data(), sizeof(T) * 4 * m, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->geom_a, ga.data(), sizeof(T) * 4 * mp, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->geom_b, gb.data(), sizeof(T) * 4 * m, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->mat_a, ma.data(), sizeof(T) * 4 * m, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->mat_b, mb.data(), sizeof(T) * 2 * m, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->mat_type, mt.data(), sizeof(int) * m, hipMemcpyHostToDevice));
-    h->n = m;
+    h->n = m; h->n_padded = mp;
     h->stats.num_spheres = m;
     return 0;
 }
 
 template <class T, class CAM>
-int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_tiles) {
+int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_tiles, unsigned long long* seg_counter = nullptr) {
     RenderParams<T> p = make_params<T>(h, cam);
-    p.bx = bx; p.by = by; p.wave_tiles = wave_tiles;
+    p.bx = bx; p.by = by; p.wave_tiles = wave_tiles; p.seg_counter = seg_counter;
     dim3 grid((p.W + bx - 1) / bx, (h->local_rows + by - 1) / by);
     dim3 block(bx * by);
-    const size_t lds = h->scene_source == RTIOW_SCENE_LDS ? sizeof(T) * 4 * (size_t)h->n : 0;
+    const size_t lds = h->scene_source == RTIOW_SCENE_LDS ? sizeof(T) * 4 * (size_t)h->n_padded : 0;
     if (lds > 160 * 1024) return fail_arg(h, RTIOW_E_BADARG, "scene too large for LDS staging; use RTIOW_SCENE_SCALAR");
     hipFuncAttributes fa{};
-    if (h->scene_source == RTIOW_SCENE_LDS) {
-        auto k = render_kernel<T, RTIOW_SCENE_LDS>;
+    if (seg_counter) {
+        auto k = h->scene_source == RTIOW_SCENE_LDS ? render_kernel<T, RTIOW_SCENE_LDS, true, 1> : render_kernel<T, RTIOW_SCENE_SCALAR, true, 1>;
+        if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, grid, block, lds, h->stream, p);
+        HIP_TRY(h, hipGetLastError());
+        return 0;
+    }
+    {
+        void (*k)(const RenderParams<T>);
+        const bool l = h->scene_source == RTIOW_SCENE_LDS;
+        // the filter's candidate queue holds 16-bit sphere indices
+        if (h->algorithm == RTIOW_ALGO_DIRECT || h->n > 65000) k = l ? render_kernel<T, RTIOW_SCENE_LDS, false, 0> : render_kernel<T, RTIOW_SCENE_SCALAR, false, 0>;
+        else k = l ? render_kernel<T, RTIOW_SCENE_LDS, false, 1> : render_kernel<T, RTIOW_SCENE_SCALAR, false, 1>;
         if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(h, hipFuncGetAttributes(&fa, (const void*)k));
         hipLaunchKernelGGL(k, grid, block, lds, h->stream, p);
-    } else {
-        auto k = render_kernel<T, RTIOW_SCENE_SCALAR>;
-        HIP_TRY(h, hipFuncGetAttributes(&fa, (const void*)k));
-        hipLaunchKernelGGL(k, grid, block, 0, h->stream, p);
     }
     HIP_TRY(h, hipGetLastError());
     h->stats.vgprs = fa.numRegs;
@@ -574,7 +708,14 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     h->stats.lds_bytes = (int)(lds + fa.sharedSizeBytes);
     h->stats.block_x = bx; h->stats.block_y = by;
     h->stats.scene_source = h->scene_source;
+    h->stats.algorithm = h->algorithm;
     return 0;
+}
+
+void block_shape(int T, int& bx, int& by, int& wave_tiles) {
+    if (T == 0) { bx = 16; by = 16; wave_tiles = 1; }       // library tiling: 4 waves, each an 8x8 tile
+    else if (T == 8) { bx = 8; by = 8; wave_tiles = 1; }    // == the reference's 8x8 block (one wave)
+    else { bx = T; by = T; wave_tiles = 0; }                 // the reference's T x T row-major block
 }
 
 }  // namespace
@@ -723,9 +864,7 @@ int rtiow_render(rtiow_handle h, int threads_per_block_row, float* kernel_ms) {
     if (rc) return rc;
     if (h->local_rows == 0) { if (kernel_ms) *kernel_ms = 0; return 0; }
     int bx, by, wave_tiles;
-    if (T == 0) { bx = 16; by = 16; wave_tiles = 1; }       // library tiling: 4 waves, each an 8x8 tile
-    else if (T == 8) { bx = 8; by = 8; wave_tiles = 1; }    // == the reference's 8x8 block (one wave)
-    else { bx = T; by = T; wave_tiles = 0; }                 // the reference's T x T row-major block
+    block_shape(T, bx, by, wave_tiles);
     if (kernel_ms) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));                     // main.cu:334
     if (h->precision == 32) rc = launch_render<float>(h, h->cam32, bx, by, wave_tiles);
     else rc = launch_render<double>(h, h->cam64, bx, by, wave_tiles);
@@ -740,6 +879,33 @@ int rtiow_render(rtiow_handle h, int threads_per_block_row, float* kernel_ms) {
         *kernel_ms = ms;
         h->stats.render_ms = ms;
     }
+    return 0;
+}
+
+int rtiow_count_segments(rtiow_handle h, int threads_per_block_row, uint64_t* segments) {
+    if (!h || !segments) return RTIOW_E_BADARG;
+    if (!h->have_camera || h->n == 0) return fail_arg(h, RTIOW_E_STATE, "rtiow_count_segments before rtiow_set_scene/rtiow_set_camera");
+    if (!h->rng_ready) return fail_arg(h, RTIOW_E_STATE, "rtiow_count_segments before rtiow_init_rng");
+    const int T = threads_per_block_row;
+    if (T < 0 || T > 32) return fail_arg(h, RTIOW_E_BADARG, "rtiow_count_segments: threads_per_block_row must be 0..32");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_framebuffer(h);
+    if (rc) return rc;
+    *segments = 0;
+    if (h->local_rows == 0) return 0;
+    unsigned long long* d = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&d, sizeof *d));
+    HIP_TRY(h, hipMemsetAsync(d, 0, sizeof *d, h->stream));
+    int bx, by, wave_tiles;
+    block_shape(T, bx, by, wave_tiles);
+    if (h->precision == 32) rc = launch_render<float>(h, h->cam32, bx, by, wave_tiles, d);
+    else rc = launch_render<double>(h, h->cam64, bx, by, wave_tiles, d);
+    if (rc) { (void)hipFree(d); return rc; }
+    unsigned long long host = 0;
+    HIP_TRY(h, hipMemcpyAsync(&host, d, sizeof host, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(d);
+    *segments = host;
     return 0;
 }
 
@@ -777,6 +943,13 @@ int rtiow_set_scene_source(rtiow_handle h, int scene_source) {
     if (!h) return RTIOW_E_BADARG;
     if (scene_source != RTIOW_SCENE_LDS && scene_source != RTIOW_SCENE_SCALAR) return fail_arg(h, RTIOW_E_BADARG, "unknown scene source");
     h->scene_source = scene_source;
+    return 0;
+}
+
+int rtiow_set_algorithm(rtiow_handle h, int algorithm) {
+    if (!h) return RTIOW_E_BADARG;
+    if (algorithm != RTIOW_ALGO_DIRECT && algorithm != RTIOW_ALGO_FILTERED) return fail_arg(h, RTIOW_E_BADARG, "unknown algorithm");
+    h->algorithm = algorithm;
     return 0;
 }
 

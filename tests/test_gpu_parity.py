@@ -1,0 +1,252 @@
+"""Parity tests proper (-m gpu): the HIP render path, called through the C-ABI, against the
+CPU oracle on the same seeded inputs.  The bar is BIT-EXACT: kernel and oracle share one
+floating-point contract (IEEE + - * / sqrt, explicit fma placements, no other contraction;
+see DESIGN.md), so every pixel's float bits must agree, in fp32 and in fp64.
+"""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.conftest import compact
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt(native):
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return native
+
+
+def _render(rt, prec, scene_id, W, H, S, B, threads=8, source=0, shard=None, seed=1227, algo=1):
+    sc = rt.build_scene(scene_id, prec)
+    with rt.Renderer(0, prec) as r:
+        r.set_camera(rt.camera(prec, W, H, S, B))
+        r.set_scene(sc)
+        r.set_scene_source(source)
+        r.set_algorithm(algo)
+        if shard:
+            r.set_shard(*shard)
+        r.init_rng(seed)
+        ms = r.render(threads)
+        assert ms > 0 or r.local_rows == 0
+        return r.read_framebuffer()
+
+
+def _oracle(oracle, rt, prec, scene_id, W, H, S, B, seed=1227, rows=None):
+    sc = compact(oracle.build_scene(scene_id, prec))
+    cam = rt.camera(prec, W, H, S, B)
+    if rows is None:
+        return oracle.render(prec, sc, cam, seed)
+    return oracle.render(prec, sc, cam, seed, rows[0], rows[1])
+
+
+def _same_bits(a, b):
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+# ---------------------------------------------------------------------------------------
+def test_native_library_is_what_runs(rt):
+    rt.load_host_library()
+    with rt.Renderer(0, 32) as r:
+        assert r._lib.rtiow_abi_version() == 1
+    maps = open("/proc/self/maps").read()
+    assert "librtiow_hip.so" in maps and "librtiow_host.so" in maps
+
+
+def test_device_arithmetic_is_ieee_like_the_host(rt, oracle):
+    rng = np.random.default_rng(7)
+    for prec, dt in ((32, np.float32), (64, np.float64)):
+        n = 1 << 16
+        mk = lambda: (rng.standard_normal(n) * 10.0 ** rng.uniform(-18, 18, n)).astype(dt)
+        a, b, c = mk(), mk(), mk()
+        # include denormal results / operands
+        a[:64] = np.array(np.finfo(dt).tiny, dt) * rng.uniform(0.01, 4, 64).astype(dt)
+        with rt.Renderer(0, prec) as r, np.errstate(all="ignore"):
+            assert _same_bits(r.debug_ops(0, a, b), (a / b).astype(dt))
+            assert _same_bits(r.debug_ops(1, np.abs(a)), np.sqrt(np.abs(a)).astype(dt))
+            fma = np.array([np.float64(x) * np.float64(y) + np.float64(z) for x, y, z in zip(a[:2048], b[:2048], c[:2048])])
+            got = r.debug_ops(2, a[:2048], b[:2048], c[:2048])
+            if prec == 32:   # double holds a float product exactly; one rounding left
+                assert _same_bits(got, fma.astype(np.float32))
+            # unfused a*b+c must NOT be contracted (-ffp-contract=off)
+            assert _same_bits(r.debug_ops(4, a, b, c), ((a * b).astype(dt) + c).astype(dt))
+    # u32 -> (0,1] float conversion, incl. the ends of the range
+    xs = np.concatenate([np.array([0, 1, 2, 0x7fffffff, 0x80000000, 0xfffffffe, 0xffffffff], np.uint32),
+                         rng.integers(0, 2 ** 32, 4096, dtype=np.uint64).astype(np.uint32)])
+    with rt.Renderer(0, 32) as r:
+        got = r.debug_ops(3, xs.view(np.float32))
+    want = (xs.astype(np.float32) * np.float32(2.0 ** -32) + np.float32(2.0 ** -33)).astype(np.float32)
+    assert _same_bits(got, want) and got.min() > 0 and got.max() <= 1.0
+
+
+def test_rng_init_matches_curand_init_semantics(rt, oracle):
+    # rtweekend.h:49: curand_init(1227, pixel_index, 0); also under sharding (GLOBAL index)
+    for W, H, shard in [(64, 40, None), (37, 19, None), (48, 40, (1, 3, 8)), (33, 21, (2, 4, 4))]:
+        with rt.Renderer(0, 32) as r:
+            r.set_camera(rt.camera(32, W, H, 1, 1))
+            if shard:
+                r.set_shard(*shard)
+            r.init_rng(1227)
+            rows = r.local_row_map()
+            got = r.debug_read_rng()
+        seqs = (rows[:, None].astype(np.int64) * W + np.arange(W)[None, :]).ravel()
+        assert np.array_equal(got, oracle.xorwow_states(1227, seqs))
+    with rt.Renderer(0, 32) as r:          # another seed, high subsequence bits
+        r.set_camera(rt.camera(32, 2048, 1100, 1, 1))
+        r.set_shard(7, 8, 8)
+        r.init_rng(0x1234567890ABCDEF)
+        rows = r.local_row_map()
+        got = r.debug_read_rng().reshape(len(rows), 2048, 6)
+    for (k, i) in [(0, 0), (5, 17), (len(rows) - 1, 2047)]:
+        st = oracle.xorwow_init(0x1234567890ABCDEF, int(rows[k]) * 2048 + i, 0)
+        assert np.array_equal(got[k, i], st)
+
+
+def test_render_matches_committed_golden_images(rt, golden_dir):
+    from tests.golden.make_golden import CUDA_SEM_CONFIGS
+    for name, prec, sid, W, H, S, B in CUDA_SEM_CONFIGS:
+        gold = np.load(os.path.join(golden_dir, name + ".npy"))
+        assert _same_bits(_render(rt, prec, sid, W, H, S, B), gold), name
+
+
+@pytest.mark.parametrize("prec,scene_id,W,H,S,B", [
+    (32, 1, 320, 192, 10, 25),      # BASELINE configs[1]
+    (32, 3, 320, 192, 10, 25),
+    (32, 2, 160, 96, 6, 50),
+    (64, 3, 160, 96, 4, 25),
+    (64, 1, 96, 64, 2, 50),
+    (32, 3, 101, 67, 3, 8),         # ragged: not a multiple of any tile
+    (32, 3, 1, 1, 5, 5),
+    (32, 3, 7, 3, 1, 1),
+    (32, 3, 64, 8, 7, 0),           # zero bounces: ray_color returns black at once
+    (64, 2, 33, 9, 2, 3),
+])
+def test_render_bit_exact_vs_oracle(rt, oracle, prec, scene_id, W, H, S, B):
+    want, stats = _oracle(oracle, rt, prec, scene_id, W, H, S, B)
+    for algo in (rt.ALGO_FILTERED, rt.ALGO_DIRECT):     # candidate filter on / reference loop as written
+        got = _render(rt, prec, scene_id, W, H, S, B, algo=algo)
+        assert _same_bits(got, want), algo
+    assert np.isfinite(got).all()
+
+
+def test_block_shapes_and_scene_sources_give_the_same_image(rt, oracle):
+    want, _ = _oracle(oracle, rt, 32, 3, 100, 60, 3, 12)
+    for threads in (0, 1, 4, 8, 16, 32):
+        for source in (rt.SCENE_LDS, rt.SCENE_SCALAR):
+            for algo in (rt.ALGO_FILTERED, rt.ALGO_DIRECT):
+                assert _same_bits(_render(rt, 32, 3, 100, 60, 3, 12, threads, source, algo=algo), want), (threads, source, algo)
+    want64, _ = _oracle(oracle, rt, 64, 3, 50, 30, 2, 12)
+    for threads in (0, 8, 16):
+        assert _same_bits(_render(rt, 64, 3, 50, 30, 2, 12, threads, rt.SCENE_SCALAR), want64)
+
+
+def test_segment_count_matches_oracle(rt, oracle):
+    for prec, sid, W, H, S, B in [(32, 3, 96, 56, 5, 25), (32, 1, 64, 40, 3, 50), (64, 2, 40, 24, 4, 10)]:
+        want, stats = _oracle(oracle, rt, prec, sid, W, H, S, B)
+        with rt.Renderer(0, prec) as r:
+            r.set_camera(rt.camera(prec, W, H, S, B)); r.set_scene(rt.build_scene(sid, prec)); r.init_rng(1227)
+            assert r.count_segments(0) == stats[1]
+            assert _same_bits(r.read_framebuffer(), want)
+
+
+def test_sharded_render_assembles_to_the_single_gpu_image(rt, oracle):
+    W, H, S, B = 96, 75, 3, 10
+    want, _ = _oracle(oracle, rt, 32, 3, W, H, S, B)
+    for nranks, strip in [(2, 8), (3, 8), (8, 8), (4, 16), (5, 1)]:
+        full = np.zeros((H, W, 3), np.float32)
+        total = 0
+        for rank in range(nranks):
+            part = _render(rt, 32, 3, W, H, S, B, threads=0, shard=(rank, nranks, strip))
+            total += part.shape[0]
+            rt.place_rows(full, part, rank, nranks, strip)
+        assert total == H and _same_bits(full, want), (nranks, strip)
+
+
+def test_external_framebuffer_and_torch_stream(rt, oracle):
+    import torch
+    from raytracingincuda_amd.distributed import StripGather
+    W, H, S, B = 80, 48, 2, 8
+    want, _ = _oracle(oracle, rt, 32, 3, W, H, S, B)
+    g = StripGather(W, H, 0, 1, 8, torch.float32, "cuda:0")
+    stream = torch.cuda.Stream()
+    with rt.Renderer(0, 32) as r, torch.cuda.stream(stream):
+        r.set_stream(stream.cuda_stream)
+        r.set_camera(rt.camera(32, W, H, S, B)); r.set_scene(rt.build_scene(3, 32)); r.init_rng(1227)
+        view = g.local_view()
+        r.bind_framebuffer(view.data_ptr(), view.numel() * 4)
+        r.render(0, sync=False)
+        full = g.gather()
+        stream.synchronize()
+    assert _same_bits(full.cpu().numpy(), want)
+
+
+def test_call_order_and_argument_errors(rt):
+    with rt.Renderer(0, 32) as r:
+        with pytest.raises(rt.RtiowError) as e:
+            r.render(8)
+        assert e.value.code == -2
+        r.set_camera(rt.camera(32, 16, 16, 1, 1))
+        r.set_scene(rt.build_scene(3, 32))
+        with pytest.raises(rt.RtiowError):
+            r.render(8)                    # RNG not initialised (main.cu:326-330 must come first)
+        r.init_rng(1227)
+        with pytest.raises(rt.RtiowError):
+            r.render(33)
+        with pytest.raises(rt.RtiowError):
+            r.set_shard(3, 2, 8)
+        r.render(8)
+    with pytest.raises(rt.RtiowError):
+        rt.Renderer(99, 32)
+    with pytest.raises((rt.RtiowError, ValueError)):
+        rt.Renderer(0, 16)
+
+
+def test_executable_is_a_drop_in(rt, oracle, tmp_path):
+    """stdout bytes, file name and P3 text of global-float-hip-raytrace (main.cu:342-343,
+    349-358, 368-379, 397-398) on BASELINE configs[1] geometry (reduced spp for the oracle)."""
+    exe = os.path.join(os.path.dirname(rt.lib_paths()["hip"]), "..", "bin", "global-float-hip-raytrace")
+    r = subprocess.run([exe, "--scene_id", "1", "--width=160", "--height", "96", "--samples", "4", "--bounces=25", "--threads", "8"],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    assert re.fullmatch(r" *\d+\.\d{8}, *\d+\.\d{8}\n", r.stdout) and len(r.stdout) == 32
+    render_ms, e2e_ms = (float(x) for x in r.stdout.split(","))
+    assert 0 < render_ms < e2e_ms
+    name = "global_float_scene1_160x96_4samples_25bounces_8threadsPerBlockRow.ppm"
+    assert os.listdir(str(tmp_path)) == [name]
+    want, _ = _oracle(oracle, rt, 32, 1, 160, 96, 4, 25)
+    assert open(str(tmp_path / name), "rb").read() == rt.format_ppm(want)
+    # defaults (main.cu:45-54) and the double variant's name (GlobalDouble main.cu:351)
+    exe64 = exe.replace("float", "double")
+    r = subprocess.run([exe64, "--scene_id=3", "--samples=1", "--bounces=2"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0
+    assert os.path.exists(str(tmp_path / "global_double_scene3_320x192_1samples_2bounces_8threadsPerBlockRow.ppm"))
+
+
+def test_full_size_properties(rt, oracle):
+    """BASELINE headline config (scene 3, 1920x1080, 100 spp, 50 bounces): too big for the
+    oracle in full, so: (1) run-to-run determinism, (2) 8-way sharded == whole image,
+    (3) oracle spot check of whole rows, (4) value range / no NaN, (5) segment statistics."""
+    W, H, S, B = 1920, 1080, 100, 50
+    sc = rt.build_scene(3, 32)
+    with rt.Renderer(0, 32) as r:
+        r.set_camera(rt.camera(32, W, H, S, B)); r.set_scene(sc); r.init_rng(1227)
+        r.render(0)
+        a = r.read_framebuffer()
+        r.render(8)
+        b = r.read_framebuffer()
+        segs = r.count_segments(0)
+    assert _same_bits(a, b)
+    assert np.isfinite(a).all() and a.min() >= 0 and a.max() <= 1.0 + 1e-6
+    assert 2.0 < segs / (W * H * S) < 2.6          # 2.24 segments per primary ray
+    full = np.zeros_like(a)
+    for rank in range(8):
+        rt.place_rows(full, _render(rt, 32, 3, W, H, S, B, threads=0, shard=(rank, 8, 8)), rank, 8, 8)
+    assert _same_bits(full, a)
+    for row in (0, 611, 1079):
+        want, _ = _oracle(oracle, rt, 32, 3, W, H, S, B, rows=(row, row + 1))
+        assert _same_bits(a[row:row + 1], want), row

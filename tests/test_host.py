@@ -1,0 +1,148 @@
+"""Host-side half of the drop-in (no GPU): scene tables, camera, PPM writer, file naming,
+CLI behaviour, and that the C-ABI libraries load and export every declared symbol."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rtiow_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_c_abi_exports_every_declared_symbol(native):
+    from raytracingincuda_amd import api
+    paths = native.lib_paths()
+    hip_decl, host_decl = _declared("rtiow.h"), _declared("rtiow_host.h")
+    assert sorted(api.HIP_SYMBOLS) == hip_decl
+    assert sorted(api.HOST_SYMBOLS) == host_decl
+    # dlopen both (no compute call: there is no GPU here) and resolve each symbol
+    hip = ctypes.CDLL(paths["hip"])
+    host = ctypes.CDLL(paths["host"])
+    for s in hip_decl:
+        assert getattr(hip, s) is not None
+    for s in host_decl:
+        assert getattr(host, s) is not None
+    assert hip.rtiow_abi_version() == 1
+    # exported from the shared objects with C linkage
+    syms = subprocess.run(["nm", "-D", "--defined-only", paths["hip"]], capture_output=True, text=True, check=True).stdout
+    for s in hip_decl:
+        assert re.search(r"\bT %s\b" % s, syms), s
+
+
+def test_no_gpu_means_loud_failure_not_fallback(native):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(native.RtiowError):
+        native.Renderer(0, 32)
+
+
+def test_product_code_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "raytracingincuda_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "liboracle" not in text and "oracle_lib" not in text and "import oracle" not in text, f
+
+
+def test_host_scene_equals_oracle_bitwise(native, oracle):
+    for prec in (32, 64):
+        for sid in (1, 2, 3, 0, -5, 99):
+            a, b = native.build_scene(sid, prec), oracle.build_scene(sid, prec)
+            assert native.scene_slots(sid) == len(b["type"])
+            for k in ("center_radius", "albedo_fuzz", "refraction_index", "type", "valid"):
+                assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), (prec, sid, k)
+    sc = native.compact_scene(native.build_scene(1, 32))
+    assert len(sc["type"]) == 487 and sc["valid"].all()
+
+
+def test_host_camera_equals_oracle_bitwise(native, oracle):
+    from tests.oracle_lib import Oracle
+    for prec in (32, 64):
+        for cfg in [(320, 192, 10, 25), (1280, 720, 100, 50), (1920, 1080, 100, 50), (1920, 1080, 500, 50), (7, 5, 1, 1)]:
+            cam = native.camera(prec, *cfg)
+            ints, flat = Oracle.camera_to_flat(cam, prec)
+            oints, oflat = oracle.camera_flat(prec, *cfg)
+            assert np.array_equal(ints, oints) and np.array_equal(flat.view(np.uint8), oflat.view(np.uint8))
+    with pytest.raises(native.RtiowError):
+        native.camera(32, 0, 10, 1, 1)
+
+
+def test_ppm_filename_matches_reference_pattern(native):
+    # main.cu:349-358 and GlobalDouble main.cu:351
+    assert native.ppm_filename(32, 1, 320, 192, 10, 25, 8) == "global_float_scene1_320x192_10samples_25bounces_8threadsPerBlockRow.ppm"
+    assert native.ppm_filename(64, 3, 1920, 1080, 500, 50, 16) == "global_double_scene3_1920x1080_500samples_50bounces_16threadsPerBlockRow.ppm"
+
+
+def test_ppm_writer_semantics(native, tmp_path, oracle):
+    # int(256*clamp(c,0,0.999)), "r g b\n", header "P3\nW H\n255\n" (main.cu:367-379)
+    for dt in (np.float32, np.float64):
+        img = np.array([[[0.0, 0.5, 1.0], [0.999, 0.9989, -0.25]], [[2.0, 1e-9, 0.25], [0.00390625, 0.0039, 0.7]]], dt)
+        text = native.format_ppm(img)
+        assert text == b"P3\n2 2\n255\n0 128 255\n255 255 0\n255 0 64\n1 0 179\n"
+        path = str(tmp_path / "x.ppm")
+        native.write_ppm(path, img)
+        assert open(path, "rb").read() == text
+    # same quantisation as the reference serial writer on a real image (color.h:40-43)
+    p3, _ = oracle.render_serial(3, 32, 18, 2, 5)
+    vals = np.array(p3.split()[4:], np.int64)
+    assert vals.min() >= 0 and vals.max() <= 255
+    with pytest.raises(native.RtiowError):
+        native.write_ppm(str(tmp_path / "no_such_dir" / "x.ppm"), np.zeros((1, 1, 3), np.float32))
+
+
+def test_shard_rows_partition_and_place_rows(native):
+    for H, n, strip in [(1080, 8, 8), (1080, 3, 8), (192, 2, 8), (50, 4, 8), (7, 3, 2), (5, 8, 8), (1080, 1, 8)]:
+        seen = []
+        full = np.zeros((H, 4, 3), np.float32)
+        want = np.arange(H * 4 * 3, dtype=np.float32).reshape(H, 4, 3)
+        for r in range(n):
+            rows = native.shard_rows(H, r, n, strip)
+            assert np.all(np.diff(rows) > 0)
+            assert all((row // strip) % n == r for row in rows)
+            seen += list(rows)
+            native.place_rows(full, np.ascontiguousarray(want[rows]), r, n, strip)
+        assert sorted(seen) == list(range(H))
+        assert np.array_equal(full, want)
+    with pytest.raises(native.RtiowError):
+        native.shard_rows(10, 3, 3, 8)
+
+
+def _exe(native, name="global-float-hip-raytrace"):
+    return os.path.join(os.path.dirname(native.lib_paths()["hip"]), "..", "bin", name)
+
+
+def test_cli_help_and_missing_scene_id(native):
+    # main.cu:62-73: --help -> usage on stdout, exit 0; no --scene_id -> message on stderr, usage on stdout, exit 1
+    for name in ("global-float-hip-raytrace", "global-double-hip-raytrace"):
+        r = subprocess.run([_exe(native, name), "--help"], capture_output=True, text=True)
+        assert r.returncode == 0 and "--scene_id arg" in r.stdout and "(default: 320)" in r.stdout and "(default: 25)" in r.stdout
+        r = subprocess.run([_exe(native, name), "-h"], capture_output=True, text=True)
+        assert r.returncode == 0 and "Print usage" in r.stdout
+        r = subprocess.run([_exe(native, name), "--width", "64"], capture_output=True, text=True)
+        assert r.returncode == 1 and r.stderr == "Error: --scene_id is required.\n" and "Usage:" in r.stdout
+
+
+def test_cli_unknown_option_aborts_like_uncaught_cxxopts(native):
+    r = subprocess.run([_exe(native), "--scene_id", "1", "--bogus", "3"], capture_output=True, text=True)
+    assert r.returncode == -6 and "does not exist" in r.stderr and r.stdout == ""
+    r = subprocess.run([_exe(native), "--scene_id", "abc"], capture_output=True, text=True)
+    assert r.returncode == -6 and r.stdout == ""
+
+
+def test_cli_device_failure_keeps_stdout_empty(native):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    # main.cu:14-21: runtime failure -> message on stderr, exit(code), nothing on stdout (empty CSV cell)
+    r = subprocess.run([_exe(native), "--scene_id=3", "--width=16", "--height=8"], capture_output=True, text=True)
+    assert r.returncode != 0 and r.stdout == "" and "HIP_SAFE_CALL" in r.stderr
