@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--precision", type=int, default=32, choices=(32, 64))
     ap.add_argument("--threads", type=int, default=0, help="reference --threads (block T x T); 0 = library tiling")
     ap.add_argument("--scene_source", default="lds", choices=("lds", "scalar"))
-    ap.add_argument("--algorithm", default="direct", choices=("filtered", "direct"))
+    ap.add_argument("--schedule", default="persistent", choices=("persistent", "static"))
     ap.add_argument("--strip_rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -119,7 +119,7 @@ def main():
     r.set_camera(cam)
     r.set_scene(scene)
     r.set_scene_source(rt.SCENE_LDS if args.scene_source == "lds" else rt.SCENE_SCALAR)
-    r.set_algorithm(rt.ALGO_FILTERED if args.algorithm == "filtered" else rt.ALGO_DIRECT)
+    r.set_schedule(rt.SCHED_PERSISTENT if args.schedule == "persistent" else rt.SCHED_STATIC)
     r.set_shard(rank, world, args.strip_rows)
     gather = StripGather(W, H, rank, world, args.strip_rows, tdtype, "cuda:%d" % local_rank)
     view = gather.local_view()
@@ -175,7 +175,7 @@ def main():
             "vs_baseline": None, "dtype": "f32" if prec == 32 else "f64", "data": "synthetic",
             "config": {"workload": "scene %d (%d spheres), %dx%d, %d spp, %d bounces, XORWOW seed 1227" % (args.scene_id, nspheres, W, H, S, B),
                        "scene_id": args.scene_id, "spheres": nspheres, "width": W, "height": H, "samples": S, "bounces": B,
-                       "threads": args.threads, "scene_source": args.scene_source, "hit_world": args.algorithm,
+                       "threads": args.threads, "scene_source": args.scene_source, "schedule": args.schedule,
                        "sharding": "interleaved %d-row strips, gather to rank 0 inside the step" % args.strip_rows if world > 1 else "none"},
             "kernel_ms_mean": round(kms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
             "kernel_ms_mean_max_over_ranks": round(kernel_mean_max, 4),

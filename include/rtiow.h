@@ -41,11 +41,14 @@ extern "C" {
 #define RTIOW_SCENE_LDS    0    /* sphere list staged into LDS per workgroup (default) */
 #define RTIOW_SCENE_SCALAR 1    /* wave-uniform scalar loads through the scalar cache  */
 
-/* hit_world strategy (both give the same image bit for bit):
- * DIRECT   = the reference loop (hittable.h:80-98): every sphere tested exactly (default);
- * FILTERED = conservative per-sphere filter + exact test of the surviving candidates. */
-#define RTIOW_ALGO_DIRECT   0
-#define RTIOW_ALGO_FILTERED 1
+/* Pixel scheduling (same image either way):
+ * STATIC     = the reference's launch geometry: grid of T x T blocks, one lane per pixel
+ *              (main.cu:137-139, camera.h:131-134);
+ * PERSISTENT = resident waves pull 64-pixel pools from a global counter and hand a new pixel
+ *              to every lane the moment it finishes one (default; --threads still sets the
+ *              workgroup size T x T). */
+#define RTIOW_SCHED_STATIC     0
+#define RTIOW_SCHED_PERSISTENT 1
 
 typedef struct rtiow_handle_s* rtiow_handle;
 
@@ -78,7 +81,8 @@ typedef struct {
     int32_t  vgprs, sgprs;       /* register use of the render kernel variant (0: unknown) */
     int32_t  lds_bytes;          /* dynamic+static LDS per workgroup of the last render    */
     int32_t  scene_source;       /* RTIOW_SCENE_*                                          */
-    int32_t  algorithm;          /* RTIOW_ALGO_*                                           */
+    int32_t  schedule;           /* RTIOW_SCHED_*                                          */
+    int32_t  grid_blocks;        /* workgroups launched by the last render                 */
 } rtiow_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------
@@ -138,7 +142,8 @@ int rtiow_read_framebuffer(rtiow_handle h, void* host_rgb, size_t bytes);
 
 /* ---- knobs / introspection */
 int rtiow_set_scene_source(rtiow_handle h, int scene_source /* RTIOW_SCENE_* */);
-int rtiow_set_algorithm(rtiow_handle h, int algorithm /* RTIOW_ALGO_* */);
+/* waves_per_simd: 0 = as many resident waves as fit; 1..8 caps them (PERSISTENT only). */
+int rtiow_set_schedule(rtiow_handle h, int schedule /* RTIOW_SCHED_* */, int waves_per_simd);
 int rtiow_get_stats(rtiow_handle h, rtiow_stats* out);
 int rtiow_synchronize(rtiow_handle h);
 

@@ -460,12 +460,13 @@ inline V3<T> dev_ray_color(V3<T> O0, V3<T> D0, int max_depth, const World<T>& w,
 
 template <class T>
 void render_cuda_semantics(const World<T>& w, const Camera<T>& cam, uint64_t seed, int row0, int row1,
-                           T* out_rgb /* (row1-row0)*W*3 */, RenderStats& st) {
+                           T* out_rgb /* (row1-row0)*W*3 */, RenderStats& st, uint32_t* seg_per_pixel = nullptr) {
     for (int j = row0; j < row1; ++j)
         for (int i = 0; i < cam.W; ++i) {
             const int pixel_index = j * cam.W + i;                    // camera.h:134
             Xorwow s; xorwow_init(s, seed, (uint64_t)pixel_index, 0); // rtweekend.h:49
             V3<T> pc = {0, 0, 0};
+            const uint64_t seg0 = st.segments;
             for (int sample = 0; sample < cam.S; ++sample) {          // camera.h:141
                 T ox = device_uniform<T>(s) - (T)0.5;                 // :145 (first argument drawn first)
                 T oy = device_uniform<T>(s) - (T)0.5;                 // :146
@@ -480,6 +481,7 @@ void render_cuda_semantics(const World<T>& w, const Camera<T>& cam, uint64_t see
                 ++st.primary_rays;
                 pc = pc + dev_ray_color<T>(org, dir, cam.B, w, s, st); // :160
             }
+            if (seg_per_pixel) seg_per_pixel[(size_t)(j - row0) * cam.W + i] = (uint32_t)(st.segments - seg0);
             pc = scale(cam.pixel_samples_scale, pc);                  // :167
             T* o = out_rgb + ((size_t)(j - row0) * cam.W + i) * 3;
             o[0] = pc.x > 0 ? (T)std::sqrt(pc.x) : 0;                 // color.h:10-13
@@ -693,6 +695,17 @@ int oracle_render(int precision, int n, const void* center_radius, const void* a
         render_cuda_semantics<double>(w, c, seed, row0, row1, (double*)out_rgb, st);
     } else return -1;
     if (stats4) { stats4[0] = st.primary_rays; stats4[1] = st.segments; stats4[2] = st.sphere_tests; stats4[3] = 0; }
+    return 0;
+}
+
+// As oracle_render (fp32) plus the number of path segments (hit_world calls) of every pixel.
+int oracle_render_segments_f32(int n, const float* center_radius, const float* albedo_fuzz, const float* ri, const int* type,
+                               const int* cam_ints4, const float* cam_flat20, unsigned long long seed, int row0, int row1,
+                               float* out_rgb, unsigned int* seg_per_pixel) {
+    RenderStats st = {0, 0, 0, 0};
+    World<float> w; world_from_arrays(n, center_radius, albedo_fuzz, ri, type, w);
+    Camera<float> c; camera_from_flat(c, cam_ints4, cam_flat20);
+    render_cuda_semantics<float>(w, c, seed, row0, row1, out_rgb, st, seg_per_pixel);
     return 0;
 }
 

@@ -22,7 +22,7 @@ import numpy as np
 
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 SCENE_LDS, SCENE_SCALAR = 0, 1
-ALGO_DIRECT, ALGO_FILTERED = 0, 1
+SCHED_STATIC, SCHED_PERSISTENT = 0, 1
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIBDIR = os.path.join(_PKG, "lib")
@@ -59,7 +59,8 @@ class Stats(ctypes.Structure):
                 ("primary_rays", ctypes.c_uint64), ("local_rows", ctypes.c_int32),
                 ("num_spheres", ctypes.c_int32), ("block_x", ctypes.c_int32), ("block_y", ctypes.c_int32),
                 ("vgprs", ctypes.c_int32), ("sgprs", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
-                ("scene_source", ctypes.c_int32), ("algorithm", ctypes.c_int32)]
+                ("scene_source", ctypes.c_int32),
+                ("schedule", ctypes.c_int32), ("grid_blocks", ctypes.c_int32)]
 
 
 # Every symbol include/rtiow.h declares (tests check that the built library exports them all).
@@ -67,7 +68,7 @@ HIP_SYMBOLS = [
     "rtiow_abi_version", "rtiow_create", "rtiow_destroy", "rtiow_last_error_string", "rtiow_set_stream",
     "rtiow_set_scene", "rtiow_set_camera", "rtiow_set_shard", "rtiow_local_rows", "rtiow_local_row_map",
     "rtiow_init_rng", "rtiow_render", "rtiow_count_segments", "rtiow_bind_framebuffer", "rtiow_framebuffer_device_ptr",
-    "rtiow_read_framebuffer", "rtiow_set_scene_source", "rtiow_set_algorithm", "rtiow_get_stats", "rtiow_synchronize",
+    "rtiow_read_framebuffer", "rtiow_set_scene_source", "rtiow_set_schedule", "rtiow_get_stats", "rtiow_synchronize",
     "rtiow_debug_read_rng", "rtiow_debug_ops",
 ]
 HOST_SYMBOLS = [
@@ -132,7 +133,7 @@ def load_hip_library():
         lib.rtiow_framebuffer_device_ptr.argtypes = [H, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
         lib.rtiow_read_framebuffer.argtypes = [H, vp, ctypes.c_size_t]
         lib.rtiow_set_scene_source.argtypes = [H, ctypes.c_int]
-        lib.rtiow_set_algorithm.argtypes = [H, ctypes.c_int]
+        lib.rtiow_set_schedule.argtypes = [H, ctypes.c_int, ctypes.c_int]
         lib.rtiow_get_stats.argtypes = [H, ctypes.POINTER(Stats)]
         lib.rtiow_synchronize.argtypes = [H]
         lib.rtiow_debug_read_rng.argtypes = [H, ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t]
@@ -314,8 +315,8 @@ class Renderer:
     def set_scene_source(self, source):
         self._check(self._lib.rtiow_set_scene_source(self._h, source))
 
-    def set_algorithm(self, algorithm):
-        self._check(self._lib.rtiow_set_algorithm(self._h, algorithm))
+    def set_schedule(self, schedule, waves_per_simd=0):
+        self._check(self._lib.rtiow_set_schedule(self._h, schedule, waves_per_simd))
 
     @property
     def local_rows(self):

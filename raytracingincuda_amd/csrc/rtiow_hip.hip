@@ -155,6 +155,8 @@ template <class T> struct RenderParams {
     int bx, by;                       // tile (block) shape in pixels
     int wave_tiles;                   // 1: lanes of a wave form 8x8 tiles inside the block
     unsigned long long* seg_counter;  // COUNT variant only: total hit_world calls (path segments)
+    unsigned int* work_counter;       // SCHED_PERSISTENT: next unassigned pixel slot (zeroed per launch)
+    int coop_offset;                  // SCHED_PERSISTENT: byte offset of the per-wave coop scratch in LDS
 };
 
 #define RT_FMA(a, b, c) Real<T>::fma((a), (b), (c))
@@ -175,17 +177,19 @@ template <class T> __device__ __forceinline__ V3<T> reflect3(V3<T> v, V3<T> n) {
     return madd3(-k, n, v);
 }
 template <class T> __device__ __forceinline__ V3<T> random_unit_vector(Rng& s) {   // vec3.h:117-127
+    // The rejection loop only finds the accepted candidate; its normalisation (an IEEE sqrt and
+    // divide, ~30 instructions) runs once after the loop instead of in every round the wave
+    // executes for its slowest lane.  Same draws, same arithmetic on the accepted candidate.
+    T x, y, z, lensq;
     for (;;) {
-        T x = RT_FMA(Real<T>::uniform(s), (T)2, (T)-1);
-        T y = RT_FMA(Real<T>::uniform(s), (T)2, (T)-1);
-        T z = RT_FMA(Real<T>::uniform(s), (T)2, (T)-1);
-        V3<T> p = {x, y, z};
-        T lensq = dot3(p, p);
-        if (Real<T>::ruv_eps < lensq && lensq <= (T)1) {
-            T inv = (T)1 / Real<T>::sqrt(lensq);
-            return scale3(inv, p);
-        }
+        x = RT_FMA(Real<T>::uniform(s), (T)2, (T)-1);
+        y = RT_FMA(Real<T>::uniform(s), (T)2, (T)-1);
+        z = RT_FMA(Real<T>::uniform(s), (T)2, (T)-1);
+        lensq = RT_FMA(z, z, RT_FMA(y, y, x * x));
+        if (Real<T>::ruv_eps < lensq && lensq <= (T)1) break;
     }
+    const T inv = (T)1 / Real<T>::sqrt(lensq);
+    return {inv * x, inv * y, inv * z};
 }
 
 // One primary ray: camera.h:145-155 (+ :73-76, vec3.h:109-115).  Also returns the y
@@ -213,41 +217,6 @@ __device__ __forceinline__ void gen_primary(const RenderParams<T>& p, int i, int
     sky_uy = inv * D.y;
 }
 
-// ---- raw hardware square root (v_sqrt_f32 / v_sqrt_f64): ~1 ulp / ~2^-23 relative.  Used ONLY
-// by the conservative candidate filter below, never for a value that reaches the image.
-__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ double fast_sqrt(double x) { return __builtin_amdgcn_sqrt(x); }
-
-template <class T, int SRC>
-__device__ __forceinline__ void load_sphere(const RenderParams<T>& p, const T* lds_geom, int s, T& cx, T& cy, T& cz, T& r2) {
-    const T* g = (SRC == RTIOW_SCENE_LDS) ? lds_geom : p.geom_a;
-    cx = g[4 * s + 0]; cy = g[4 * s + 1]; cz = g[4 * s + 2]; r2 = g[4 * s + 3];
-}
-
-// hit_sphere (hittable.h:40-57) for sphere `s` against the running (closest, hit) pair,
-// exactly as the reference evaluates it (IEEE sqrt and divisions).
-template <class T, int SRC>
-__device__ __forceinline__ void exact_sphere_test(const RenderParams<T>& p, const T* lds_geom, int s, V3<T> O, V3<T> D, T a,
-                                                  T& closest, int& hit) {
-    T cx, cy, cz, r2;
-    load_sphere<T, SRC>(p, lds_geom, s, cx, cy, cz, r2);
-    const T tmin = (T)0.001;
-    const T ocx = cx - O.x, ocy = cy - O.y, ocz = cz - O.z;               // :42
-    const T h = RT_FMA(D.z, ocz, RT_FMA(D.y, ocy, D.x * ocx));          // :44
-    const T c = RT_FMA(ocz, ocz, RT_FMA(ocy, ocy, ocx * ocx)) - r2;     // :45
-    const T disc = RT_FMA(h, h, -(a * c));                              // :47
-    if (disc >= (T)0) {                                                 // :48
-        const T sq = Real<T>::sqrt(disc);                               // :50
-        T root = (h - sq) / a;                                          // :53
-        bool ok = (tmin < root) && (root < closest);                    // :54
-        if (!ok) {
-            root = (h + sq) / a;                                        // :55
-            ok = (tmin < root) && (root < closest);                     // :56
-        }
-        if (ok) { closest = root; hit = s; }                            // hittable.h:88-92
-    }
-}
-
 // Second half of hit_sphere (hittable.h:50-57) once the discriminant is known to be >= 0.
 template <class T>
 __device__ __forceinline__ void finish_sphere_test(int s, T h, T disc, T a, T& closest, int& hit) {
@@ -262,111 +231,275 @@ __device__ __forceinline__ void finish_sphere_test(int s, T h, T disc, T a, T& c
     if (ok) { closest = root; hit = s; }                            // hittable.h:88-92
 }
 
-// hit_world (hittable.h:80-98), ALGO 0: every sphere tested exactly, in index order.
-// The table is padded to a multiple of 4 with never-hit entries (r^2 = -1e12 => disc < 0), so
-// the loop runs 4 spheres per trip: 4 x 12 VALU for the discriminants (hittable.h:42-47),
-// ONE wave-level branch on max(disc0..3) >= 0 (a lane rarely reaches a sphere's line, ~4 % of
-// the trips for the reference scenes), and the IEEE sqrt/divide tail only inside it.
+// First half of hit_sphere (hittable.h:42-47) for the four spheres s..s+3 of one trip:
+// h = d.oc and disc = h*h - a*c, each element with exactly the reference's operation sequence.
+//
+// fp32: the table is PAIR-INTERLEAVED -- {cxA,cxB, cyA,cyB, czA,czB, r2A,r2B} per pair of
+// spheres -- so the twelve operations run as v_pk_add/mul/fma_f32 on two spheres at once:
+// 24 packed VALU per trip instead of 48 (per-element IEEE results are unchanged).
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <class T> struct Trip { T h0, h1, h2, h3, d0, d1, d2, d3; };
+
+// The ray as the sphere loop wants it: fp32 keeps every component splatted over a register
+// pair (the second operand of the packed instructions), fp64 keeps plain scalars.
+template <class T> struct LoopRay;
+template <> struct LoopRay<float> { v2f ox, oy, oz, dx, dy, dz, aa; float a; };
+template <> struct LoopRay<double> { double ox, oy, oz, dx, dy, dz, a; };
+
+__device__ __forceinline__ LoopRay<float> make_loop_ray(float ox, float oy, float oz, float dx, float dy, float dz, float a) {
+    // The empty asm makes each component an opaque VGPR value, so the splats are built with
+    // register moves (hipcc otherwise round-trips the ray through scratch to form the pairs).
+    asm volatile("" : "+v"(ox), "+v"(oy), "+v"(oz), "+v"(dx), "+v"(dy), "+v"(dz), "+v"(a));
+    LoopRay<float> r;
+    r.ox.x = ox; r.ox.y = ox; r.oy.x = oy; r.oy.y = oy; r.oz.x = oz; r.oz.y = oz;
+    r.dx.x = dx; r.dx.y = dx; r.dy.x = dy; r.dy.y = dy; r.dz.x = dz; r.dz.y = dz;
+    r.aa.x = a; r.aa.y = a; r.a = a;
+    return r;
+}
+__device__ __forceinline__ LoopRay<double> make_loop_ray(double ox, double oy, double oz, double dx, double dy, double dz, double a) {
+    return {ox, oy, oz, dx, dy, dz, a};
+}
+
+__device__ __forceinline__ void pair_discriminants(v4f lo, v4f hi, const LoopRay<float>& r, v2f& hh, v2f& dd) {
+    const v2f cx = {lo.x, lo.y}, cy = {lo.z, lo.w}, cz = {hi.x, hi.y}, r2 = {hi.z, hi.w};
+    const v2f ocx = cx - r.ox, ocy = cy - r.oy, ocz = cz - r.oz;                                    // :42
+    hh = __builtin_elementwise_fma(r.dz, ocz, __builtin_elementwise_fma(r.dy, ocy, r.dx * ocx));    // :44
+    const v2f c = __builtin_elementwise_fma(ocz, ocz, __builtin_elementwise_fma(ocy, ocy, ocx * ocx)) - r2;   // :45
+    dd = __builtin_elementwise_fma(hh, hh, -(r.aa * c));                                            // :47
+}
+
+__device__ __forceinline__ Trip<float> trip_discriminants(const float* g, int s, const LoopRay<float>& r) {
+    const v4f* g4 = reinterpret_cast<const v4f*>(g + 4 * s);
+    const v4f p0 = g4[0], p1 = g4[1], p2 = g4[2], p3 = g4[3];
+    v2f ha, da, hb, db;
+    pair_discriminants(p0, p1, r, ha, da);
+    pair_discriminants(p2, p3, r, hb, db);
+    return {ha.x, ha.y, hb.x, hb.y, da.x, da.y, db.x, db.y};
+}
+
+// fp64: plain {cx,cy,cz,r2} per sphere (no packed f64 on gfx950).
+__device__ __forceinline__ void sphere_discriminant(const double* g, int s, const LoopRay<double>& r, double& h, double& disc) {
+    const double cx = g[4 * s + 0], cy = g[4 * s + 1], cz = g[4 * s + 2], r2 = g[4 * s + 3];
+    const double ocx = cx - r.ox, ocy = cy - r.oy, ocz = cz - r.oz;                    // :42
+    h = __builtin_fma(r.dz, ocz, __builtin_fma(r.dy, ocy, r.dx * ocx));                // :44
+    const double c = __builtin_fma(ocz, ocz, __builtin_fma(ocy, ocy, ocx * ocx)) - r2; // :45
+    disc = __builtin_fma(h, h, -(r.a * c));                                            // :47
+}
+__device__ __forceinline__ Trip<double> trip_discriminants(const double* g, int s, const LoopRay<double>& r) {
+    Trip<double> t;
+    sphere_discriminant(g, s + 0, r, t.h0, t.d0);
+    sphere_discriminant(g, s + 1, r, t.h1, t.d1);
+    sphere_discriminant(g, s + 2, r, t.h2, t.d2);
+    sphere_discriminant(g, s + 3, r, t.h3, t.d3);
+    return t;
+}
+
+// One trip = four spheres: discriminants, ONE wave-level branch on max(disc0..3) >= 0 (a lane
+// reaches a sphere's line in only ~4 % of the trips for the reference scenes), and the IEEE
+// sqrt/divide tail only inside it, in index order.
+template <class T>
+__device__ __forceinline__ void sphere_trip(const T* g, int s, const LoopRay<T>& r, T& closest, int& hit) {
+    const Trip<T> t = trip_discriminants(g, s, r);
+    const T m = Real<T>::fmax(Real<T>::fmax(t.d0, t.d1), Real<T>::fmax(t.d2, t.d3));
+    if (m >= (T)0) {                                                          // :48 for any of the four
+        if (t.d0 >= (T)0) finish_sphere_test<T>(s + 0, t.h0, t.d0, r.a, closest, hit);
+        if (t.d1 >= (T)0) finish_sphere_test<T>(s + 1, t.h1, t.d1, r.a, closest, hit);
+        if (t.d2 >= (T)0) finish_sphere_test<T>(s + 2, t.h2, t.d2, r.a, closest, hit);
+        if (t.d3 >= (T)0) finish_sphere_test<T>(s + 3, t.h3, t.d3, r.a, closest, hit);
+    }
+}
+
+// hit_world (hittable.h:80-98): every sphere tested exactly, in index order.  The table is
+// padded to a multiple of 4 with never-hit entries (r^2 = -1e12 => disc < 0).
 template <class T, int SRC>
 __device__ __forceinline__ void hit_world_direct(const RenderParams<T>& p, const T* lds_geom, V3<T> O, V3<T> D, T a,
                                                  T& closest, int& hit) {
     const T* g = (SRC == RTIOW_SCENE_LDS) ? lds_geom : p.geom_a;
-    for (int s = 0; s < p.n_padded; s += 4) {
-        T h[4], disc[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const T cx = g[4 * (s + k) + 0], cy = g[4 * (s + k) + 1], cz = g[4 * (s + k) + 2], r2 = g[4 * (s + k) + 3];
-            const T ocx = cx - O.x, ocy = cy - O.y, ocz = cz - O.z;               // :42
-            h[k] = RT_FMA(D.z, ocz, RT_FMA(D.y, ocy, D.x * ocx));                 // :44
-            const T c = RT_FMA(ocz, ocz, RT_FMA(ocy, ocy, ocx * ocx)) - r2;       // :45
-            disc[k] = RT_FMA(h[k], h[k], -(a * c));                               // :47
-        }
-        const T m = Real<T>::fmax(Real<T>::fmax(disc[0], disc[1]), Real<T>::fmax(disc[2], disc[3]));
-        if (m >= (T)0) {                                                          // :48 for any of the four
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (disc[k] >= (T)0) finish_sphere_test<T>(s + k, h[k], disc[k], a, closest, hit);
-        }
-    }
+    const LoopRay<T> r = make_loop_ray(O.x, O.y, O.z, D.x, D.y, D.z, a);
+    for (int s = 0; s < p.n_padded; s += 4) sphere_trip<T>(g, s, r, closest, hit);
 }
 
-// hit_world, ALGO 1: same result bit for bit, two phases.
-//  Phase 1 walks all spheres with the reference's own discriminant arithmetic and DROPS a
-//  sphere only when it provably cannot change (closest, hit) in the exact loop:
-//    (behind)  h <= 0 and a*c > 0  =>  sqrt(disc) <= |h| in IEEE arithmetic, both roots <= 0 < tmin;
-//    (far)     a lower bound of its near-root numerator h - sqrt(disc) exceeds an upper bound
-//              `ub` of the numerator of a root the exact loop has provably accepted earlier
-//              (all roots of one ray share the divisor a > 0, so numerators order like roots).
-//  The bounds use the raw v_sqrt (error <= 2^-22 relative) inside a 2^-20 guard band, so a
-//  sphere whose status is in doubt is always kept.  Survivors go to a 4-entry per-lane queue.
-//  Phase 2 drains the queue in index order through exact_sphere_test: the dropped spheres
-//  are no-ops of the exact loop, so (closest, hit) is what hit_world_direct returns.
-//  The IEEE sqrt + 2 divisions (~45 instructions) thus run once per queue slot per wave
-//  instead of once per sphere per wave.  DESIGN.md §"Candidate filter" has the proofs.
+// Per-lane path state of the flattened samples x bounces loop.
+template <class T> struct PathState {
+    V3<T> O, D, atten, acc;
+    T sky_uy;
+    int sample, depth;
+    Rng rs;
+};
+
+// Everything after hit_world in one trip of the loop at camera.h:84: sky on a miss
+// (camera.h:120-124), else hit record + scatter (camera.h:88-117).  Returns true when the
+// path ended; `col` is then its colour.
+template <class T>
+__device__ __forceinline__ bool shade_step(const RenderParams<T>& p, PathState<T>& st, T closest, int hit, V3<T>& col) {
+    col = {0, 0, 0};
+    const V3<T> O = st.O, D = st.D;
+    if (hit < 0) {
+        // ------------ sky, from the PRIMARY ray (camera.h:120-124)
+        const double a_sky = 0.5 * ((double)st.sky_uy + 1.0);
+        const T w1 = (T)(1.0 - a_sky), w2 = (T)a_sky;
+        const V3<T> sky = {RT_FMA(w2, (T)0.5, w1), RT_FMA(w2, (T)0.7, w1), RT_FMA(w2, (T)1.0, w1)};
+        col = {st.atten.x * sky.x, st.atten.y * sky.y, st.atten.z * sky.z};
+        return true;
+    }
+    // ------------ complete the hit record (hittable.h:59-63, :21-26)
+    const T* gb = p.geom_b + 4 * (size_t)hit;
+    const V3<T> C = {gb[0], gb[1], gb[2]};
+    const T inv_r = gb[3];
+    const V3<T> P = madd3(closest, D, O);
+    const V3<T> outward = {inv_r * (P.x - C.x), inv_r * (P.y - C.y), inv_r * (P.z - C.z)};
+    const bool front = dot3(D, outward) < (T)0;
+    const V3<T> nrm = front ? outward : V3<T>{-outward.x, -outward.y, -outward.z};
+    const int mtype = p.mat_type[hit];
+    const T* ma = p.mat_a + 4 * (size_t)hit;
+    V3<T> nd;
+    V3<T> att = {ma[0], ma[1], ma[2]};
+    bool ok = true;
+    if (mtype == RTIOW_DIELECTRIC) {                                     // material.h:68-89
+        att = {1, 1, 1};
+        const T* mb = p.mat_b + 2 * (size_t)hit;
+        const T ri = front ? mb[1] : mb[0];
+        const V3<T> ud = unit3(D);
+        const T cos_theta = Real<T>::fmin(-dot3(ud, nrm), (T)1);
+        const T sin_theta = Real<T>::sqrt(RT_FMA(-cos_theta, cos_theta, (T)1));
+        bool reflect_it = ri * sin_theta > (T)1;
+        if (!reflect_it) {
+            T r0 = ((T)1 - ri) / ((T)1 + ri);                           // material.h:62-66
+            r0 = r0 * r0;
+            const float x = (float)((T)1 - cos_theta);
+            const float x2 = x * x;
+            const float p5 = (x2 * x2) * x;                              // powf(x,5), see DESIGN.md
+            const T refl = RT_FMA((T)1 - r0, (T)p5, r0);
+            reflect_it = refl > Real<T>::uniform(st.rs);
+        }
+        if (reflect_it) {
+            nd = reflect3(ud, nrm);
+        } else {                                                         // vec3.h:133-138
+            const V3<T> perp = scale3(ri, madd3(cos_theta, nrm, ud));
+            const T k = -Real<T>::sqrt(Real<T>::fabs((T)1 - dot3(perp, perp)));
+            nd = madd3(k, nrm, perp);
+        }
+    } else {
+        const V3<T> ruv = random_unit_vector<T>(st.rs);
+        if (mtype == RTIOW_LAMBERTIAN) {                                 // material.h:38-49
+            nd = {nrm.x + ruv.x, nrm.y + ruv.y, nrm.z + ruv.z};
+            const T e = Real<T>::near_zero;
+            if (Real<T>::fabs(nd.x) < e && Real<T>::fabs(nd.y) < e && Real<T>::fabs(nd.z) < e) nd = nrm;
+        } else {                                                         // material.h:51-59
+            const V3<T> ur = unit3(reflect3(D, nrm));
+            nd = madd3(ma[3], ruv, ur);
+            ok = dot3(nd, nrm) > (T)0;
+        }
+    }
+    if (!ok) return true;                                                // camera.h:117
+    st.atten = {st.atten.x * att.x, st.atten.y * att.y, st.atten.z * att.z};   // camera.h:110-115
+    st.O = P; st.D = nd;
+    ++st.depth;
+    return false;
+}
+
+// One path segment (one trip of the loop at camera.h:84) done by the lane alone.
 template <class T, int SRC>
-__device__ __forceinline__ void hit_world_filtered(const RenderParams<T>& p, const T* lds_geom, V3<T> O, V3<T> D, T a,
-                                                   T& closest, int& hit) {
-    const T kappa = (T)9.5367431640625e-07;                 // 2^-20 guard band
-    const T tmin_hi = ((T)0.001 * a) * (T)1.00000095367431640625;   // tmin*a*(1+2^-20): "near root provably > tmin"
-    T ub = __builtin_huge_val();                            // numerator bound of a provably accepted root
-    unsigned q_lo = 0xffffffffu, q_hi = 0xffffffffu;        // 4 x 16-bit sphere indices, 0xffff = empty
-
-    auto drain = [&]() {
-#pragma unroll
-        for (int slot = 3; slot >= 0; --slot) {             // oldest entry first = index order
-            const unsigned e = ((slot >= 2 ? q_hi : q_lo) >> ((slot & 1) * 16)) & 0xffffu;
-            if (e != 0xffffu) exact_sphere_test<T, SRC>(p, lds_geom, (int)e, O, D, a, closest, hit);
-        }
-        q_lo = q_hi = 0xffffffffu;
-        if (hit >= 0) {                                      // exact closest tightens the bound
-            const T cb = (closest * a) * (T)1.00000095367431640625;
-            ub = cb < ub ? cb : ub;
-        }
-    };
-
-    for (int s = 0; s < p.n; ++s) {
-        T cx, cy, cz, r2;
-        load_sphere<T, SRC>(p, lds_geom, s, cx, cy, cz, r2);
-        const T ocx = cx - O.x, ocy = cy - O.y, ocz = cz - O.z;
-        const T h = RT_FMA(D.z, ocz, RT_FMA(D.y, ocy, D.x * ocx));
-        const T c = RT_FMA(ocz, ocz, RT_FMA(ocy, ocy, ocx * ocx)) - r2;
-        const T nac = -(a * c);
-        const T disc = RT_FMA(h, h, nac);
-        // keep unless (disc < 0) or (behind: h <= 0 and a*c > 0); NaNs are kept
-        const T in_front = Real<T>::fmin(disc, h);
-        const T keep = in_front > nac ? in_front : nac;
-        if (!(keep < (T)0)) {
-            const T sq = fast_sqrt(disc);
-            const T e = RT_FMA(kappa, Real<T>::fabs(h) + sq, (T)1e-30);
-            const T n1 = h - sq;
-            const T n1_lo = n1 - e;
-            if (!(n1_lo > ub)) {                             // not provably farther: enqueue
-                q_hi = __builtin_amdgcn_alignbit(q_hi, q_lo, 16);
-                q_lo = (q_lo << 16) | (unsigned)s;
-                const T n1_hi = (n1 + e) * (T)1.00000095367431640625;
-                if (n1_lo > tmin_hi) ub = n1_hi < ub ? n1_hi : ub;
-                if (__builtin_amdgcn_ballot_w64(q_hi < 0xffff0000u) != 0) drain();   // some lane's queue is full
-            }
-        }
-    }
-    drain();
+__device__ __forceinline__ bool segment_step(const RenderParams<T>& p, const T* lds_geom, PathState<T>& st, V3<T>& col) {
+    if (st.depth >= p.B) { col = {0, 0, 0}; return true; }   // camera.h:127 (also B <= 0)
+    // ---------------- hit_world (hittable.h:80-98), nearest (t, index) only
+    T closest = __builtin_huge_val();
+    int hit = -1;
+    const T a = dot3(st.D, st.D);                 // hittable.h:43, ray-invariant
+    hit_world_direct<T, SRC>(p, lds_geom, st.O, st.D, a, closest, hit);
+    return shade_step<T>(p, st, closest, hit, col);
 }
 
-template <class T, int SRC, bool COUNT, int ALGO>
-__global__ void __launch_bounds__(1024)
-render_kernel(const RenderParams<T> p) {
+// ---- cooperative hit_world for the drain tail of the persistent kernel.
+// When the work pool is empty and n <= 32 lanes of a wave still carry a path, the wave's
+// idle lanes help: the n rays are published in LDS, each ray is served by a group of
+// g = 2^floor(log2(lanes/n)) lanes that split the 4-sphere trips of hit_world_direct between
+// them, and the partial nearest hits are reduced with xor-shuffles.  The nearest hit of
+// the reference loop is the lexicographic minimum of (t, index) over the spheres -- a
+// sphere's accepted root does not depend on closest_so_far except through `root < closest`
+// (hittable.h:53-57) -- so any partition + min-reduction returns exactly what the
+// sequential loop returns.  This cuts the latency of one segment from N sphere tests to
+// N/g, which is what bounds the kernel once only the long glass paths are left.
+template <class T> struct CoopSlot { T ox, oy, oz, a, dx, dy, dz, pad; };
+
+template <class T, int SRC>
+__device__ __forceinline__ void hit_world_coop(const RenderParams<T>& p, const T* lds_geom, CoopSlot<T>* slots,
+                                               bool alive, unsigned long long alive_mask, int n_alive, int wave_lanes,
+                                               V3<T> O, V3<T> D, T a, T& closest, int& hit) {
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(alive_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)alive_mask, 0u));
+    int lg = 0;                                    // g = 2^lg lanes per ray, n_alive * g <= lanes of this wave
+    while ((n_alive << (lg + 1)) <= wave_lanes) ++lg;
+    const int g = 1 << lg;
+    if (alive) slots[rank] = {O.x, O.y, O.z, a, D.x, D.y, D.z, (T)0};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int group = lane >> lg, sub = lane & (g - 1);
+    T best = __builtin_huge_val();
+    int best_idx = -1;
+    if (group < n_alive) {
+        const CoopSlot<T> cs = slots[group];
+        const LoopRay<T> r = make_loop_ray(cs.ox, cs.oy, cs.oz, cs.dx, cs.dy, cs.dz, cs.a);
+        const T* gm = (SRC == RTIOW_SCENE_LDS) ? lds_geom : p.geom_a;
+        for (int s = sub * 4; s < p.n_padded; s += g * 4) sphere_trip<T>(gm, s, r, best, best_idx);
+    }
+    // lexicographic (t, index) minimum over the g lanes of the group
+    for (int off = 1; off < g; off <<= 1) {
+        const T ot = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(best_idx, off, 64);
+        const bool take = (ot < best) || (ot == best && (unsigned)oi < (unsigned)best_idx);
+        best = take ? ot : best;
+        best_idx = take ? oi : best_idx;
+    }
+    // owner of slot k reads lane k*g
+    const T rt = __shfl(best, rank << lg, 64);
+    const int ri = __shfl(best_idx, rank << lg, 64);
+    if (alive) { closest = rt; hit = ri; }
+}
+
+template <class T>
+__device__ __forceinline__ void load_rng(const RenderParams<T>& p, size_t lp, Rng& rs) {   // camera.h:136
+    const size_t npix = (size_t)p.W * p.local_rows;
+    rs.v0 = p.rng[0 * npix + lp]; rs.v1 = p.rng[1 * npix + lp]; rs.v2 = p.rng[2 * npix + lp];
+    rs.v3 = p.rng[3 * npix + lp]; rs.v4 = p.rng[4 * npix + lp]; rs.d = p.rng[5 * npix + lp];
+}
+
+// camera.h:167-171, color.h:10-13.  The RNG state is deliberately not written back.
+template <class T>
+__device__ __forceinline__ void store_pixel(const RenderParams<T>& p, size_t lp, V3<T> acc) {
+    acc = scale3(p.pixel_samples_scale, acc);
+    T* o = p.fb + lp * 3;
+    o[0] = acc.x > (T)0 ? Real<T>::sqrt(acc.x) : (T)0;
+    o[1] = acc.y > (T)0 ? Real<T>::sqrt(acc.y) : (T)0;
+    o[2] = acc.z > (T)0 ? Real<T>::sqrt(acc.z) : (T)0;
+}
+
+template <class T, int SRC>
+__device__ __forceinline__ T* stage_scene(const RenderParams<T>& p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* lds_geom = reinterpret_cast<T*>(smem_raw);
-
-    const int tid = threadIdx.x;
-    const int nthreads = blockDim.x;
     if (SRC == RTIOW_SCENE_LDS) {
         // Stage {cx,cy,cz,r^2} for all spheres: coalesced global reads, one pass.
-        for (int k = tid; k < p.n_padded * 4; k += nthreads) lds_geom[k] = p.geom_a[k];
+        for (int k = threadIdx.x; k < p.n_padded * 4; k += blockDim.x) lds_geom[k] = p.geom_a[k];
         __syncthreads();
     }
+    return lds_geom;
+}
 
-    // lane -> pixel
+__device__ __forceinline__ int global_row(int jl, int strip_rows, int nranks, int rank) {
+    return ((jl / strip_rows) * nranks + rank) * strip_rows + (jl % strip_rows);
+}
+
+// ---- SCHED_STATIC: the reference's launch geometry, one lane = one pixel of a T x T block
+// (camera.h:131-134), with the flattened sample/bounce loop.
+template <class T, int SRC, bool COUNT>
+__global__ void __launch_bounds__(1024)
+render_kernel(const RenderParams<T> p) {
+    const T* lds_geom = stage_scene<T, SRC>(p);
+    const int tid = threadIdx.x;
     int tx, ty;
     if (p.wave_tiles) {
         const int wave = tid >> 6, lane = tid & 63;
@@ -380,119 +513,133 @@ render_kernel(const RenderParams<T> p) {
     const int i = blockIdx.x * p.bx + tx;
     const int jl = blockIdx.y * p.by + ty;      // local row
     if (i >= p.W || jl >= p.local_rows) return; // camera.h:133
-    const int j = ((jl / p.strip_rows) * p.nranks + p.rank) * p.strip_rows + (jl % p.strip_rows);
+    const int j = global_row(jl, p.strip_rows, p.nranks, p.rank);
     const size_t lp = (size_t)jl * p.W + i;
-    const size_t npix = (size_t)p.W * p.local_rows;
 
-    Rng rs;                                      // camera.h:136
-    rs.v0 = p.rng[0 * npix + lp]; rs.v1 = p.rng[1 * npix + lp]; rs.v2 = p.rng[2 * npix + lp];
-    rs.v3 = p.rng[3 * npix + lp]; rs.v4 = p.rng[4 * npix + lp]; rs.d = p.rng[5 * npix + lp];
-
-    V3<T> acc = {0, 0, 0};
-    const int S = p.S, B = p.B;
-
-    V3<T> O, D, atten;
-    T sky_uy;
-    int sample = 0, depth = 0;
+    PathState<T> st;
+    load_rng(p, lp, st.rs);
+    st.acc = {0, 0, 0};
+    st.sample = 0; st.depth = 0;
     unsigned int nseg = 0;
-    if (S > 0) { gen_primary(p, i, j, rs, O, D, sky_uy); atten = {1, 1, 1}; }
+    const int S = p.S;
+    bool fresh = true;                            // the lane needs a primary ray (camera.h:141-155)
 
-    while (sample < S) {
-        bool terminated;
-        V3<T> col = {0, 0, 0};
-        if (depth >= B) {
-            terminated = true;                   // camera.h:127 (also B <= 0)
-        } else {
-            // ---------------- hit_world (hittable.h:80-98), nearest (t, index) only
-            T closest = __builtin_huge_val();
-            int hit = -1;
-            const T a = dot3(D, D);              // hittable.h:43, ray-invariant
-            if (COUNT) ++nseg;
-            if (ALGO == 0) hit_world_direct<T, SRC>(p, lds_geom, O, D, a, closest, hit);
-            else hit_world_filtered<T, SRC>(p, lds_geom, O, D, a, closest, hit);
+    while (st.sample < S) {
+        if (fresh) { gen_primary(p, i, j, st.rs, st.O, st.D, st.sky_uy); st.atten = {1, 1, 1}; fresh = false; }
+        V3<T> col;
+        if (COUNT && st.depth < p.B) ++nseg;
+        if (segment_step<T, SRC>(p, lds_geom, st, col)) {
+            st.acc = {st.acc.x + col.x, st.acc.y + col.y, st.acc.z + col.z};       // camera.h:160
+            ++st.sample;
+            st.depth = 0;
+            fresh = true;
+        }
+    }
+    if (COUNT) atomicAdd(p.seg_counter, (unsigned long long)nseg);
+    store_pixel(p, lp, st.acc);
+}
 
-            if (hit < 0) {
-                // ------------ sky, from the PRIMARY ray (camera.h:120-124)
-                const double a_sky = 0.5 * ((double)sky_uy + 1.0);
-                const T w1 = (T)(1.0 - a_sky), w2 = (T)a_sky;
-                const V3<T> sky = {RT_FMA(w2, (T)0.5, w1), RT_FMA(w2, (T)0.7, w1), RT_FMA(w2, (T)1.0, w1)};
-                col = {atten.x * sky.x, atten.y * sky.y, atten.z * sky.z};
-                terminated = true;
-            } else {
-                // ------------ complete the hit record (hittable.h:59-63, :21-26)
-                const T* gb = p.geom_b + 4 * (size_t)hit;
-                const V3<T> C = {gb[0], gb[1], gb[2]};
-                const T inv_r = gb[3];
-                const V3<T> P = madd3(closest, D, O);
-                const V3<T> outward = {inv_r * (P.x - C.x), inv_r * (P.y - C.y), inv_r * (P.z - C.z)};
-                const bool front = dot3(D, outward) < (T)0;
-                const V3<T> nrm = front ? outward : V3<T>{-outward.x, -outward.y, -outward.z};
-                const int mtype = p.mat_type[hit];
-                const T* ma = p.mat_a + 4 * (size_t)hit;
-                V3<T> nd;
-                V3<T> att = {ma[0], ma[1], ma[2]};
-                bool ok = true;
-                if (mtype == RTIOW_DIELECTRIC) {                                     // material.h:68-89
-                    att = {1, 1, 1};
-                    const T* mb = p.mat_b + 2 * (size_t)hit;
-                    const T ri = front ? mb[1] : mb[0];
-                    const V3<T> ud = unit3(D);
-                    const T cos_theta = Real<T>::fmin(-dot3(ud, nrm), (T)1);
-                    const T sin_theta = Real<T>::sqrt(RT_FMA(-cos_theta, cos_theta, (T)1));
-                    bool reflect_it = ri * sin_theta > (T)1;
-                    if (!reflect_it) {
-                        T r0 = ((T)1 - ri) / ((T)1 + ri);                           // material.h:62-66
-                        r0 = r0 * r0;
-                        const float x = (float)((T)1 - cos_theta);
-                        const float x2 = x * x;
-                        const float p5 = (x2 * x2) * x;                              // powf(x,5), see DESIGN.md
-                        const T refl = RT_FMA((T)1 - r0, (T)p5, r0);
-                        reflect_it = refl > Real<T>::uniform(rs);
-                    }
-                    if (reflect_it) {
-                        nd = reflect3(ud, nrm);
-                    } else {                                                         // vec3.h:133-138
-                        const V3<T> perp = scale3(ri, madd3(cos_theta, nrm, ud));
-                        const T k = -Real<T>::sqrt(Real<T>::fabs((T)1 - dot3(perp, perp)));
-                        nd = madd3(k, nrm, perp);
-                    }
-                } else {
-                    const V3<T> ruv = random_unit_vector<T>(rs);
-                    if (mtype == RTIOW_LAMBERTIAN) {                                 // material.h:38-49
-                        nd = {nrm.x + ruv.x, nrm.y + ruv.y, nrm.z + ruv.z};
-                        const T e = Real<T>::near_zero;
-                        if (Real<T>::fabs(nd.x) < e && Real<T>::fabs(nd.y) < e && Real<T>::fabs(nd.z) < e) nd = nrm;
-                    } else {                                                         // material.h:51-59
-                        const V3<T> ur = unit3(reflect3(D, nrm));
-                        nd = madd3(ma[3], ruv, ur);
-                        ok = dot3(nd, nrm) > (T)0;
-                    }
+// ---- SCHED_PERSISTENT: lanes are not bound to pixels.  Each wave keeps a pool of 64 pixel
+// slots (one 8x8 tile) taken from a global counter; a lane that finishes its pixel takes the
+// next slot at once (ballot + mbcnt hand-out, no memory traffic), so no lane waits for the
+// longest path of a tile-mate and the grid is balanced across CUs by construction.  Slots run
+// tile-major from the BOTTOM of the image up (ground and spheres first, cheap sky last) to
+// keep the drain tail short.  Per-pixel work and RNG streams are unchanged => same image.
+constexpr int POOL = 64;
+
+template <class T, int SRC, bool COUNT>
+__global__ void __launch_bounds__(1024)
+render_persistent_kernel(const RenderParams<T> p) {
+    const T* lds_geom = stage_scene<T, SRC>(p);
+    // per-wave scratch for hit_world_coop, behind the staged geometry
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    CoopSlot<T>* coop_slots = reinterpret_cast<CoopSlot<T>*>(smem_raw + p.coop_offset) + (threadIdx.x >> 6) * 64;
+    const int tiles_x = (p.W + 7) >> 3, tiles_y = (p.local_rows + 7) >> 3;
+    const int total_slots = tiles_x * tiles_y * POOL;
+    const int S = p.S;
+
+    PathState<T> st;
+    st.acc = {0, 0, 0};
+    st.sample = 0; st.depth = 0;
+    bool alive = false, fresh = false;
+    int i = 0, j = 0;
+    size_t lp = 0;
+    unsigned int nseg = 0;
+    int pool_next = 0, pool_end = 0;             // wave-uniform
+    bool exhausted = false;                      // wave-uniform
+    const int lanes_left = (int)blockDim.x - (int)(threadIdx.x & ~63u);
+    const int wave_lanes = lanes_left < 64 ? lanes_left : 64;   // partial last wave of a T x T block
+
+    for (;;) {
+        if (!exhausted && __builtin_amdgcn_ballot_w64(!alive) != 0) {
+            bool want = !alive;
+            for (;;) {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
+                if (m == 0) break;
+                if (pool_next >= pool_end) {     // refill the wave's pool: one atomic per 64 pixels
+                    int base = 0;
+                    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) base = (int)atomicAdd(p.work_counter, (unsigned)POOL);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= total_slots) { exhausted = true; break; }
+                    pool_next = base; pool_end = base + POOL;
                 }
-                if (ok) {                                                            // camera.h:110-115
-                    atten = {atten.x * att.x, atten.y * att.y, atten.z * att.z};
-                    O = P; D = nd;
-                    ++depth;
-                    terminated = false;
-                } else {
-                    terminated = true;                                               // camera.h:117
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                const int avail = pool_end - pool_next;
+                const int wanted = __builtin_popcountll(m);
+                const bool take = want && rank < avail;
+                const int slot = pool_next + rank;
+                pool_next += wanted < avail ? wanted : avail;
+                if (take) {
+                    const int t = slot >> 6, within = slot & 63;
+                    const int ty = tiles_y - 1 - t / tiles_x, tx = t % tiles_x;
+                    i = tx * 8 + (within & 7);
+                    const int jl = ty * 8 + (within >> 3);
+                    if (i < p.W && jl < p.local_rows) {          // padded slots of ragged tiles are skipped
+                        want = false;
+                        j = global_row(jl, p.strip_rows, p.nranks, p.rank);
+                        lp = (size_t)jl * p.W + i;
+                        load_rng(p, lp, st.rs);
+                        st.acc = {0, 0, 0};
+                        st.sample = 0; st.depth = 0;
+                        if (S > 0) { alive = true; fresh = true; }
+                        else { store_pixel(p, lp, st.acc); want = true; }   // zero samples: black pixel
+                    }
                 }
             }
         }
-        if (terminated) {
-            acc = {acc.x + col.x, acc.y + col.y, acc.z + col.z};                     // camera.h:160
-            ++sample;
-            depth = 0;
-            if (sample < S) { gen_primary(p, i, j, rs, O, D, sky_uy); atten = {1, 1, 1}; }
+        const unsigned long long alive_mask = __builtin_amdgcn_ballot_w64(alive);
+        if (alive_mask == 0) break;
+        // one site generates every primary ray: first sample of a new pixel or the next sample
+        if (alive && fresh) { gen_primary(p, i, j, st.rs, st.O, st.D, st.sky_uy); st.atten = {1, 1, 1}; fresh = false; }
+        bool terminated = false;
+        V3<T> col = {0, 0, 0};
+        if (exhausted && 2 * __builtin_popcountll(alive_mask) <= wave_lanes) {
+            // drain tail: idle lanes share the survivors' sphere loops (hit_world_coop)
+            const bool need_hit = alive && st.depth < p.B;
+            const unsigned long long hit_mask = __builtin_amdgcn_ballot_w64(need_hit);
+            T closest = __builtin_huge_val();
+            int hit = -1;
+            if (hit_mask != 0) {
+                const T a = dot3(st.D, st.D);
+                hit_world_coop<T, SRC>(p, lds_geom, coop_slots, need_hit, hit_mask, __builtin_popcountll(hit_mask), wave_lanes, st.O, st.D, a, closest, hit);
+            }
+            if (alive) {
+                if (COUNT && need_hit) ++nseg;
+                terminated = need_hit ? shade_step<T>(p, st, closest, hit, col) : true;   // camera.h:127 at the depth limit
+            }
+        } else if (alive) {
+            if (COUNT && st.depth < p.B) ++nseg;
+            terminated = segment_step<T, SRC>(p, lds_geom, st, col);
+        }
+        if (alive && terminated) {
+            st.acc = {st.acc.x + col.x, st.acc.y + col.y, st.acc.z + col.z};       // camera.h:160
+            ++st.sample;
+            st.depth = 0;
+            if (st.sample < S) fresh = true;
+            else { store_pixel(p, lp, st.acc); alive = false; }
         }
     }
-
     if (COUNT) atomicAdd(p.seg_counter, (unsigned long long)nseg);
-    // camera.h:167-171, color.h:10-13.  RNG state is deliberately not written back.
-    acc = scale3(p.pixel_samples_scale, acc);
-    T* o = p.fb + lp * 3;
-    o[0] = acc.x > (T)0 ? Real<T>::sqrt(acc.x) : (T)0;
-    o[1] = acc.y > (T)0 ? Real<T>::sqrt(acc.y) : (T)0;
-    o[2] = acc.z > (T)0 ? Real<T>::sqrt(acc.z) : (T)0;
 }
 
 // Elementwise arithmetic probes (tests compare these with the host bit for bit).
@@ -576,7 +723,10 @@ struct rtiow_handle_s {
     bool fb_external = false;
     // knobs / stats
     int scene_source = RTIOW_SCENE_LDS;
-    int algorithm = RTIOW_ALGO_DIRECT;
+    int schedule = RTIOW_SCHED_PERSISTENT;
+    int waves_per_simd = 0;
+    int num_cus = 256;
+    unsigned int* work_counter = nullptr;
     rtiow_stats stats{};
 };
 
@@ -659,6 +809,12 @@ int upload_scene(rtiow_handle_s* h, int n, const T* cr, const T* af, const T* ri
     if (m == 0) return fail_arg(h, RTIOW_E_BADARG, "scene has no valid spheres");
     const int mp = (m + 3) / 4 * 4;
     for (int i = m; i < mp; ++i) ga.insert(ga.end(), {(T)0, (T)0, (T)0, (T)-1e12});   // c = |oc|^2 + 1e12 => disc < 0: never hit
+    if (sizeof(T) == 4) {                                    // fp32: pair-interleave for v_pk_*_f32 (trip_discriminants)
+        std::vector<T> pi(ga.size());
+        for (int q = 0; q < mp / 2; ++q)
+            for (int k = 0; k < 4; ++k) { pi[8 * q + 2 * k] = ga[8 * q + k]; pi[8 * q + 2 * k + 1] = ga[8 * q + 4 + k]; }
+        ga.swap(pi);
+    }
     void** bufs[] = {&h->geom_a, &h->geom_b, &h->mat_a, &h->mat_b, (void**)&h->mat_type};
     for (void** b : bufs) if (*b) { HIP_TRY(h, hipFree(*b)); *b = nullptr; }
     HIP_TRY(h, hipMalloc(&h->geom_a, sizeof(T) * 4 * mp));
@@ -676,39 +832,64 @@ int upload_scene(rtiow_handle_s* h, int n, const T* cr, const T* af, const T* ri
     return 0;
 }
 
+template <class T> using RenderFn = void (*)(const RenderParams<T>);
+
+template <class T, int SRC, bool COUNT>
+RenderFn<T> pick_sched(bool persistent) {
+    return persistent ? render_persistent_kernel<T, SRC, COUNT> : render_kernel<T, SRC, COUNT>;
+}
+template <class T>
+RenderFn<T> pick_kernel(bool persistent, bool lds, bool count) {
+    if (lds) return count ? pick_sched<T, RTIOW_SCENE_LDS, true>(persistent) : pick_sched<T, RTIOW_SCENE_LDS, false>(persistent);
+    return count ? pick_sched<T, RTIOW_SCENE_SCALAR, true>(persistent) : pick_sched<T, RTIOW_SCENE_SCALAR, false>(persistent);
+}
+
 template <class T, class CAM>
 int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_tiles, unsigned long long* seg_counter = nullptr) {
     RenderParams<T> p = make_params<T>(h, cam);
     p.bx = bx; p.by = by; p.wave_tiles = wave_tiles; p.seg_counter = seg_counter;
-    dim3 grid((p.W + bx - 1) / bx, (h->local_rows + by - 1) / by);
-    dim3 block(bx * by);
-    const size_t lds = h->scene_source == RTIOW_SCENE_LDS ? sizeof(T) * 4 * (size_t)h->n_padded : 0;
+    const bool persistent = h->schedule == RTIOW_SCHED_PERSISTENT;
+    const int threads = bx * by;
+    size_t lds = h->scene_source == RTIOW_SCENE_LDS ? sizeof(T) * 4 * (size_t)h->n_padded : 0;
+    p.coop_offset = (int)lds;                                // a multiple of 16 (n_padded % 4 == 0)
+    if (persistent) lds += (size_t)((threads + 63) / 64) * 64 * sizeof(CoopSlot<T>);
     if (lds > 160 * 1024) return fail_arg(h, RTIOW_E_BADARG, "scene too large for LDS staging; use RTIOW_SCENE_SCALAR");
+    RenderFn<T> k = pick_kernel<T>(persistent, h->scene_source == RTIOW_SCENE_LDS, seg_counter != nullptr);
+    if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipFuncAttributes fa{};
-    if (seg_counter) {
-        auto k = h->scene_source == RTIOW_SCENE_LDS ? render_kernel<T, RTIOW_SCENE_LDS, true, 1> : render_kernel<T, RTIOW_SCENE_SCALAR, true, 1>;
-        if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, grid, block, lds, h->stream, p);
-        HIP_TRY(h, hipGetLastError());
-        return 0;
+    HIP_TRY(h, hipFuncGetAttributes(&fa, (const void*)k));
+    dim3 grid, block(threads);
+    if (persistent) {
+        if (!h->work_counter) HIP_TRY(h, hipMalloc((void**)&h->work_counter, sizeof(unsigned int)));
+        HIP_TRY(h, hipMemsetAsync(h->work_counter, 0, sizeof(unsigned int), h->stream));
+        p.work_counter = h->work_counter;
+        int per_cu = 0;
+        HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, threads, lds));
+        if (per_cu < 1) per_cu = 1;
+        const int waves_per_block = (threads + 63) / 64;
+        if (h->waves_per_simd > 0) {                       // knob: fewer resident waves, more pixels per lane
+            const int cap = (h->waves_per_simd * 4 + waves_per_block - 1) / waves_per_block;
+            if (cap < per_cu) per_cu = cap;
+        }
+        const long long slots = (long long)((p.W + 7) / 8) * ((h->local_rows + 7) / 8) * POOL;
+        long long blocks = (long long)h->num_cus * per_cu;
+        const long long useful = (slots + (long long)waves_per_block * POOL - 1) / ((long long)waves_per_block * POOL);
+        if (blocks > useful) blocks = useful;               // never more waves than 64-pixel pools
+        grid = dim3((unsigned)blocks);
+    } else {
+        grid = dim3((p.W + bx - 1) / bx, (h->local_rows + by - 1) / by);
     }
-    {
-        void (*k)(const RenderParams<T>);
-        const bool l = h->scene_source == RTIOW_SCENE_LDS;
-        // the filter's candidate queue holds 16-bit sphere indices
-        if (h->algorithm == RTIOW_ALGO_DIRECT || h->n > 65000) k = l ? render_kernel<T, RTIOW_SCENE_LDS, false, 0> : render_kernel<T, RTIOW_SCENE_SCALAR, false, 0>;
-        else k = l ? render_kernel<T, RTIOW_SCENE_LDS, false, 1> : render_kernel<T, RTIOW_SCENE_SCALAR, false, 1>;
-        if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(h, hipFuncGetAttributes(&fa, (const void*)k));
-        hipLaunchKernelGGL(k, grid, block, lds, h->stream, p);
-    }
+    hipLaunchKernelGGL(k, grid, block, lds, h->stream, p);
     HIP_TRY(h, hipGetLastError());
-    h->stats.vgprs = fa.numRegs;
-    h->stats.sgprs = 0;
-    h->stats.lds_bytes = (int)(lds + fa.sharedSizeBytes);
-    h->stats.block_x = bx; h->stats.block_y = by;
-    h->stats.scene_source = h->scene_source;
-    h->stats.algorithm = h->algorithm;
+    if (!seg_counter) {
+        h->stats.vgprs = fa.numRegs;
+        h->stats.sgprs = 0;
+        h->stats.lds_bytes = (int)(lds + fa.sharedSizeBytes);
+        h->stats.block_x = bx; h->stats.block_y = by;
+        h->stats.scene_source = h->scene_source;
+        h->stats.schedule = h->schedule;
+        h->stats.grid_blocks = (int)(grid.x * grid.y);
+    }
     return 0;
 }
 
@@ -741,6 +922,8 @@ int rtiow_create(int device, int precision, rtiow_handle* out) {
         return (int)e;
     }
     h->own_stream = true;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
     *out = h;
     return 0;
 }
@@ -749,7 +932,7 @@ int rtiow_destroy(rtiow_handle h) {
     if (!h) return RTIOW_E_BADARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->geom_a, h->geom_b, h->mat_a, h->mat_b, h->mat_type, h->rng, h->jump, h->fb_external ? nullptr : h->fb};
+    void* bufs[] = {h->geom_a, h->geom_b, h->mat_a, h->mat_b, h->mat_type, h->rng, h->jump, h->work_counter, h->fb_external ? nullptr : h->fb};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -946,10 +1129,11 @@ int rtiow_set_scene_source(rtiow_handle h, int scene_source) {
     return 0;
 }
 
-int rtiow_set_algorithm(rtiow_handle h, int algorithm) {
+int rtiow_set_schedule(rtiow_handle h, int schedule, int waves_per_simd) {
     if (!h) return RTIOW_E_BADARG;
-    if (algorithm != RTIOW_ALGO_DIRECT && algorithm != RTIOW_ALGO_FILTERED) return fail_arg(h, RTIOW_E_BADARG, "unknown algorithm");
-    h->algorithm = algorithm;
+    if ((schedule != RTIOW_SCHED_STATIC && schedule != RTIOW_SCHED_PERSISTENT) || waves_per_simd < 0 || waves_per_simd > 8)
+        return fail_arg(h, RTIOW_E_BADARG, "rtiow_set_schedule: unknown schedule or waves_per_simd outside 0..8");
+    h->schedule = schedule; h->waves_per_simd = waves_per_simd;
     return 0;
 }
 

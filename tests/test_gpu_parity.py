@@ -22,13 +22,13 @@ def rt(native):
     return native
 
 
-def _render(rt, prec, scene_id, W, H, S, B, threads=8, source=0, shard=None, seed=1227, algo=1):
+def _render(rt, prec, scene_id, W, H, S, B, threads=8, source=0, shard=None, seed=1227, sched=1, wps=0):
     sc = rt.build_scene(scene_id, prec)
     with rt.Renderer(0, prec) as r:
         r.set_camera(rt.camera(prec, W, H, S, B))
         r.set_scene(sc)
         r.set_scene_source(source)
-        r.set_algorithm(algo)
+        r.set_schedule(sched, wps)
         if shard:
             r.set_shard(*shard)
         r.init_rng(seed)
@@ -128,9 +128,9 @@ def test_render_matches_committed_golden_images(rt, golden_dir):
 ])
 def test_render_bit_exact_vs_oracle(rt, oracle, prec, scene_id, W, H, S, B):
     want, stats = _oracle(oracle, rt, prec, scene_id, W, H, S, B)
-    for algo in (rt.ALGO_FILTERED, rt.ALGO_DIRECT):     # candidate filter on / reference loop as written
-        got = _render(rt, prec, scene_id, W, H, S, B, algo=algo)
-        assert _same_bits(got, want), algo
+    for sched in (rt.SCHED_PERSISTENT, rt.SCHED_STATIC):
+        got = _render(rt, prec, scene_id, W, H, S, B, sched=sched)
+        assert _same_bits(got, want), sched
     assert np.isfinite(got).all()
 
 
@@ -138,8 +138,9 @@ def test_block_shapes_and_scene_sources_give_the_same_image(rt, oracle):
     want, _ = _oracle(oracle, rt, 32, 3, 100, 60, 3, 12)
     for threads in (0, 1, 4, 8, 16, 32):
         for source in (rt.SCENE_LDS, rt.SCENE_SCALAR):
-            for algo in (rt.ALGO_FILTERED, rt.ALGO_DIRECT):
-                assert _same_bits(_render(rt, 32, 3, 100, 60, 3, 12, threads, source, algo=algo), want), (threads, source, algo)
+            for sched, wps in ((rt.SCHED_PERSISTENT, 0), (rt.SCHED_PERSISTENT, 1), (rt.SCHED_STATIC, 0)):
+                got = _render(rt, 32, 3, 100, 60, 3, 12, threads, source, sched=sched, wps=wps)
+                assert _same_bits(got, want), (threads, source, sched, wps)
     want64, _ = _oracle(oracle, rt, 64, 3, 50, 30, 2, 12)
     for threads in (0, 8, 16):
         assert _same_bits(_render(rt, 64, 3, 50, 30, 2, 12, threads, rt.SCENE_SCALAR), want64)
