@@ -99,10 +99,17 @@ def main():
         raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # RTIOW_BENCH_BACKEND=gloo is a REHEARSAL mode for boxes with fewer GPUs than ranks (ranks
+    # share devices, the gather bounces through the host); the real multi-GPU run uses RCCL.
+    backend = os.environ.get("RTIOW_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     import raytracingincuda_amd as rt
     from raytracingincuda_amd.distributed import StripGather
@@ -113,7 +120,7 @@ def main():
     scene = rt.build_scene(args.scene_id, prec)
     cam = rt.camera(prec, W, H, S, B)
 
-    r = rt.Renderer(local_rank, prec)
+    r = rt.Renderer(device_index, prec)
     stream = torch.cuda.current_stream()
     r.set_stream(stream.cuda_stream)
     r.set_camera(cam)
@@ -121,7 +128,7 @@ def main():
     r.set_scene_source(rt.SCENE_LDS if args.scene_source == "lds" else rt.SCENE_SCALAR)
     r.set_schedule(rt.SCHED_PERSISTENT if args.schedule == "persistent" else rt.SCHED_STATIC)
     r.set_shard(rank, world, args.strip_rows)
-    gather = StripGather(W, H, rank, world, args.strip_rows, tdtype, "cuda:%d" % local_rank)
+    gather = StripGather(W, H, rank, world, args.strip_rows, tdtype, "cuda:%d" % device_index, stage_via_cpu=(backend != "nccl"))
     view = gather.local_view()
     r.bind_framebuffer(view.data_ptr(), view.numel() * view.element_size())
     r.init_rng(1227)                                   # untimed, like main.cu:326-330
@@ -176,7 +183,8 @@ def main():
             "config": {"workload": "scene %d (%d spheres), %dx%d, %d spp, %d bounces, XORWOW seed 1227" % (args.scene_id, nspheres, W, H, S, B),
                        "scene_id": args.scene_id, "spheres": nspheres, "width": W, "height": H, "samples": S, "bounces": B,
                        "threads": args.threads, "scene_source": args.scene_source, "schedule": args.schedule,
-                       "sharding": "interleaved %d-row strips, gather to rank 0 inside the step" % args.strip_rows if world > 1 else "none"},
+                       "sharding": "interleaved %d-row strips, gather to rank 0 inside the step" % args.strip_rows if world > 1 else "none",
+                       "backend": backend if world > 1 else None},
             "kernel_ms_mean": round(kms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
             "kernel_ms_mean_max_over_ranks": round(kernel_mean_max, 4),
             "segments_per_ray": round(segments_total / rays, 4),
@@ -184,7 +192,7 @@ def main():
                          "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args),
                          "algorithmic_flops_per_launch": flops, "algorithmic_hbm_bytes_per_launch": fb_bytes,
                          "hbm_achieved_GBps": round(fb_bytes / (kms * 1e-3) / 1e9, 3), "hbm_peak_GBps": HBM_PEAK_GBS,
-                         "kernel": "render_kernel<%s>" % ("float" if prec == 32 else "double")},
+                         "kernel": "%s<%s>" % ("render_persistent_kernel" if args.schedule == "persistent" else "render_kernel", "float" if prec == 32 else "double")},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)

@@ -152,6 +152,10 @@ int rtiow_synchronize(rtiow_handle h);
  * parity tests compare bit-for-bit with the host (op: 0 a/b, 1 sqrt(a), 2 fma(a,b,c),
  * 3 uniform(u32 a -> T), 4 a*b+c unfused). */
 int rtiow_debug_read_rng(rtiow_handle h, uint32_t* host_states, size_t count_words);
+/* Per-wave timeline of one (untimed, counting) persistent render: 8 words per wave
+ * {t_start, t_pool_exhausted, t_end (100 MHz ticks), iterations alone, iterations cooperative,
+ * pixels taken, 0, 0}. */
+int rtiow_debug_timeline(rtiow_handle h, int threads_per_block_row, uint64_t* out_words, size_t cap_words, int* waves);
 int rtiow_debug_ops(rtiow_handle h, int op, size_t n, const void* a, const void* b, const void* c, void* out);
 
 #ifdef __cplusplus

@@ -69,7 +69,7 @@ HIP_SYMBOLS = [
     "rtiow_set_scene", "rtiow_set_camera", "rtiow_set_shard", "rtiow_local_rows", "rtiow_local_row_map",
     "rtiow_init_rng", "rtiow_render", "rtiow_count_segments", "rtiow_bind_framebuffer", "rtiow_framebuffer_device_ptr",
     "rtiow_read_framebuffer", "rtiow_set_scene_source", "rtiow_set_schedule", "rtiow_get_stats", "rtiow_synchronize",
-    "rtiow_debug_read_rng", "rtiow_debug_ops",
+    "rtiow_debug_read_rng", "rtiow_debug_timeline", "rtiow_debug_ops",
 ]
 HOST_SYMBOLS = [
     "rtiow_host_scene_slots", "rtiow_host_build_scene", "rtiow_host_camera", "rtiow_host_ppm_filename",
@@ -137,6 +137,7 @@ def load_hip_library():
         lib.rtiow_get_stats.argtypes = [H, ctypes.POINTER(Stats)]
         lib.rtiow_synchronize.argtypes = [H]
         lib.rtiow_debug_read_rng.argtypes = [H, ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t]
+        lib.rtiow_debug_timeline.argtypes = [H, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
         lib.rtiow_debug_ops.argtypes = [H, ctypes.c_int, ctypes.c_size_t, vp, vp, vp, vp]
         _hip = lib
     return _hip
@@ -377,6 +378,12 @@ class Renderer:
         out = np.zeros((n, 6), np.uint32)
         self._check(self._lib.rtiow_debug_read_rng(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), out.size))
         return out
+
+    def debug_timeline(self, threads=0):
+        out = np.zeros((16384, 8), np.uint64)
+        n = ctypes.c_int(0)
+        self._check(self._lib.rtiow_debug_timeline(self._h, int(threads), out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), out.size, ctypes.byref(n)))
+        return out[: n.value]
 
     def debug_ops(self, op, a, b=None, c=None):
         a = np.ascontiguousarray(a, self.dtype)

@@ -157,6 +157,7 @@ template <class T> struct RenderParams {
     unsigned long long* seg_counter;  // COUNT variant only: total hit_world calls (path segments)
     unsigned int* work_counter;       // SCHED_PERSISTENT: next unassigned pixel slot (zeroed per launch)
     int coop_offset;                  // SCHED_PERSISTENT: byte offset of the per-wave coop scratch in LDS
+    unsigned long long* timeline;     // COUNT variant, optional: per wave {t_start, t_exhausted, t_end, iters_normal, iters_coop, pixels, 0, 0}
 };
 
 #define RT_FMA(a, b, c) Real<T>::fma((a), (b), (c))
@@ -567,6 +568,9 @@ render_persistent_kernel(const RenderParams<T> p) {
     unsigned int nseg = 0;
     int pool_next = 0, pool_end = 0;             // wave-uniform
     bool exhausted = false;                      // wave-uniform
+    unsigned long long t_start = 0, t_exh = 0;
+    unsigned int it_normal = 0, it_coop = 0, n_pixels = 0;
+    if (COUNT) t_start = __builtin_amdgcn_s_memrealtime();
     const int lanes_left = (int)blockDim.x - (int)(threadIdx.x & ~63u);
     const int wave_lanes = lanes_left < 64 ? lanes_left : 64;   // partial last wave of a T x T block
 
@@ -580,7 +584,7 @@ render_persistent_kernel(const RenderParams<T> p) {
                     int base = 0;
                     if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) base = (int)atomicAdd(p.work_counter, (unsigned)POOL);
                     base = __builtin_amdgcn_readfirstlane(base);
-                    if (base >= total_slots) { exhausted = true; break; }
+                    if (base >= total_slots) { exhausted = true; if (COUNT) t_exh = __builtin_amdgcn_s_memrealtime(); break; }
                     pool_next = base; pool_end = base + POOL;
                 }
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -601,6 +605,7 @@ render_persistent_kernel(const RenderParams<T> p) {
                         load_rng(p, lp, st.rs);
                         st.acc = {0, 0, 0};
                         st.sample = 0; st.depth = 0;
+                        if (COUNT) ++n_pixels;
                         if (S > 0) { alive = true; fresh = true; }
                         else { store_pixel(p, lp, st.acc); want = true; }   // zero samples: black pixel
                     }
@@ -615,6 +620,7 @@ render_persistent_kernel(const RenderParams<T> p) {
         V3<T> col = {0, 0, 0};
         if (exhausted && 2 * __builtin_popcountll(alive_mask) <= wave_lanes) {
             // drain tail: idle lanes share the survivors' sphere loops (hit_world_coop)
+            if (COUNT) ++it_coop;
             const bool need_hit = alive && st.depth < p.B;
             const unsigned long long hit_mask = __builtin_amdgcn_ballot_w64(need_hit);
             T closest = __builtin_huge_val();
@@ -627,9 +633,12 @@ render_persistent_kernel(const RenderParams<T> p) {
                 if (COUNT && need_hit) ++nseg;
                 terminated = need_hit ? shade_step<T>(p, st, closest, hit, col) : true;   // camera.h:127 at the depth limit
             }
-        } else if (alive) {
-            if (COUNT && st.depth < p.B) ++nseg;
-            terminated = segment_step<T, SRC>(p, lds_geom, st, col);
+        } else {
+            if (COUNT) ++it_normal;
+            if (alive) {
+                if (COUNT && st.depth < p.B) ++nseg;
+                terminated = segment_step<T, SRC>(p, lds_geom, st, col);
+            }
         }
         if (alive && terminated) {
             st.acc = {st.acc.x + col.x, st.acc.y + col.y, st.acc.z + col.z};       // camera.h:160
@@ -639,7 +648,17 @@ render_persistent_kernel(const RenderParams<T> p) {
             else { store_pixel(p, lp, st.acc); alive = false; }
         }
     }
-    if (COUNT) atomicAdd(p.seg_counter, (unsigned long long)nseg);
+    if (COUNT) {
+        atomicAdd(p.seg_counter, (unsigned long long)nseg);
+        if (p.timeline) {
+            unsigned int px = n_pixels;
+            for (int off = 32; off > 0; off >>= 1) px += __shfl_xor(px, off, 64);
+            if ((threadIdx.x & 63) == 0) {
+                unsigned long long* o = p.timeline + 8ull * ((unsigned long long)blockIdx.x * ((blockDim.x + 63) >> 6) + (threadIdx.x >> 6));
+                o[0] = t_start; o[1] = t_exh; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = it_normal; o[4] = it_coop; o[5] = px; o[6] = 0; o[7] = 0;
+            }
+        }
+    }
 }
 
 // Elementwise arithmetic probes (tests compare these with the host bit for bit).
@@ -726,7 +745,9 @@ struct rtiow_handle_s {
     int schedule = RTIOW_SCHED_PERSISTENT;
     int waves_per_simd = 0;
     int num_cus = 256;
+    int last_count_blocks = 0;
     unsigned int* work_counter = nullptr;
+    unsigned long long* timeline = nullptr;   // debug: set only during rtiow_debug_timeline
     rtiow_stats stats{};
 };
 
@@ -851,6 +872,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     const bool persistent = h->schedule == RTIOW_SCHED_PERSISTENT;
     const int threads = bx * by;
     size_t lds = h->scene_source == RTIOW_SCENE_LDS ? sizeof(T) * 4 * (size_t)h->n_padded : 0;
+    p.timeline = seg_counter ? h->timeline : nullptr;
     p.coop_offset = (int)lds;                                // a multiple of 16 (n_padded % 4 == 0)
     if (persistent) lds += (size_t)((threads + 63) / 64) * 64 * sizeof(CoopSlot<T>);
     if (lds > 160 * 1024) return fail_arg(h, RTIOW_E_BADARG, "scene too large for LDS staging; use RTIOW_SCENE_SCALAR");
@@ -881,6 +903,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     }
     hipLaunchKernelGGL(k, grid, block, lds, h->stream, p);
     HIP_TRY(h, hipGetLastError());
+    if (seg_counter) h->last_count_blocks = (int)(grid.x * grid.y);
     if (!seg_counter) {
         h->stats.vgprs = fa.numRegs;
         h->stats.sgprs = 0;
@@ -1161,6 +1184,28 @@ int rtiow_debug_read_rng(rtiow_handle h, uint32_t* host_states, size_t count_wor
     for (size_t p = 0; p < npix; ++p)
         for (int k = 0; k < 6; ++k) host_states[p * 6 + k] = soa[k * npix + p];
     return 0;
+}
+
+int rtiow_debug_timeline(rtiow_handle h, int threads_per_block_row, uint64_t* out_words, size_t cap_words, int* waves) {
+    if (!h || !out_words || !waves) return RTIOW_E_BADARG;
+    if (h->schedule != RTIOW_SCHED_PERSISTENT) return fail_arg(h, RTIOW_E_STATE, "rtiow_debug_timeline needs RTIOW_SCHED_PERSISTENT");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t max_waves = 16384;
+    HIP_TRY(h, hipMalloc((void**)&h->timeline, max_waves * 8 * sizeof(unsigned long long)));
+    HIP_TRY(h, hipMemset(h->timeline, 0, max_waves * 8 * sizeof(unsigned long long)));
+    uint64_t seg = 0;
+    int rc = rtiow_count_segments(h, threads_per_block_row, &seg);
+    if (rc == 0) {
+        const int T = threads_per_block_row == 0 ? 16 : threads_per_block_row;
+        const size_t nw = (size_t)h->last_count_blocks * ((T * T + 63) / 64);
+        *waves = (int)nw;
+        const size_t words = nw * 8 < cap_words ? nw * 8 : cap_words;
+        hipError_t e = hipMemcpy(out_words, h->timeline, words * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(h, e, __FILE__, __LINE__);
+    }
+    (void)hipFree(h->timeline);
+    h->timeline = nullptr;
+    return rc;
 }
 
 int rtiow_debug_ops(rtiow_handle h, int op, size_t n, const void* a, const void* b, const void* c, void* out) {

@@ -24,9 +24,12 @@ class StripGather:
     largest); `row_index` is the de-interleave permutation applied on dst after the gather.
     """
 
-    def __init__(self, width, height, rank, nranks, strip_rows=8, dtype=torch.float32, device="cpu", dst=0, group=None):
+    def __init__(self, width, height, rank, nranks, strip_rows=8, dtype=torch.float32, device="cpu", dst=0, group=None,
+                 stage_via_cpu=False):
         self.width, self.height, self.rank, self.nranks = width, height, rank, nranks
         self.strip_rows, self.dst, self.group = strip_rows, dst, group
+        # rehearsal only: a gloo group cannot gather device tensors, so bounce through the host
+        self.stage_via_cpu = stage_via_cpu and str(device) != "cpu"
         self.rows = shard_rows(height, rank, nranks, strip_rows)
         self.pad_rows = max_local_rows(height, nranks, strip_rows)
         self.send = torch.zeros((self.pad_rows, width, 3), dtype=dtype, device=device)
@@ -46,7 +49,15 @@ class StripGather:
         if self.nranks == 1:
             self.full.index_copy_(0, self.index[0], self.send[: len(self.rows)])
             return self.full
-        dist.gather(self.send, self.recv if self.rank == self.dst else None, dst=self.dst, group=self.group)
+        if self.stage_via_cpu:
+            send = self.send.cpu()
+            recv = [torch.empty_like(send) for _ in range(self.nranks)] if self.rank == self.dst else None
+            dist.gather(send, recv, dst=self.dst, group=self.group)
+            if self.rank == self.dst:
+                for r in range(self.nranks):
+                    self.recv[r].copy_(recv[r])
+        else:
+            dist.gather(self.send, self.recv if self.rank == self.dst else None, dst=self.dst, group=self.group)
         if self.rank != self.dst:
             return None
         for r in range(self.nranks):
