@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--precision", type=int, default=32, choices=(32, 64))
     ap.add_argument("--threads", type=int, default=0, help="reference --threads (block T x T); 0 = library tiling")
     ap.add_argument("--scene_source", default="lds", choices=("lds", "scalar"))
-    ap.add_argument("--schedule", default="persistent", choices=("persistent", "static"))
+    ap.add_argument("--schedule", default="sorted", choices=("sorted", "persistent", "static"))
     ap.add_argument("--strip_rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -126,7 +126,7 @@ def main():
     r.set_camera(cam)
     r.set_scene(scene)
     r.set_scene_source(rt.SCENE_LDS if args.scene_source == "lds" else rt.SCENE_SCALAR)
-    r.set_schedule(rt.SCHED_PERSISTENT if args.schedule == "persistent" else rt.SCHED_STATIC)
+    r.set_schedule({"sorted": rt.SCHED_SORTED, "persistent": rt.SCHED_PERSISTENT, "static": rt.SCHED_STATIC}[args.schedule])
     r.set_shard(rank, world, args.strip_rows)
     gather = StripGather(W, H, rank, world, args.strip_rows, tdtype, "cuda:%d" % device_index, stage_via_cpu=(backend != "nccl"))
     view = gather.local_view()
@@ -192,7 +192,7 @@ def main():
                          "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args),
                          "algorithmic_flops_per_launch": flops, "algorithmic_hbm_bytes_per_launch": fb_bytes,
                          "hbm_achieved_GBps": round(fb_bytes / (kms * 1e-3) / 1e9, 3), "hbm_peak_GBps": HBM_PEAK_GBS,
-                         "kernel": "%s<%s>" % ("render_persistent_kernel" if args.schedule == "persistent" else "render_kernel", "float" if prec == 32 else "double")},
+                         "kernel": "%s<%s>" % ("render_kernel" if args.schedule == "static" else "render_persistent_kernel", "float" if prec == 32 else "double")},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)

@@ -45,10 +45,15 @@ extern "C" {
  * STATIC     = the reference's launch geometry: grid of T x T blocks, one lane per pixel
  *              (main.cu:137-139, camera.h:131-134);
  * PERSISTENT = resident waves pull 64-pixel pools from a global counter and hand a new pixel
- *              to every lane the moment it finishes one (default; --threads still sets the
+ *              to every lane the moment it finishes one (--threads still sets the
  *              workgroup size T x T). */
 #define RTIOW_SCHED_STATIC     0
 #define RTIOW_SCHED_PERSISTENT 1
+/* SORTED = PERSISTENT in two phases: the first few samples of every pixel are rendered and
+ * their path-segment counts recorded; the pixels are then ranked heavy-first into balanced
+ * pools and the remaining samples rendered in that order (RNG state and colour sum carried
+ * exactly, so the image is unchanged).  Removes the drain tail of late heavy pixels. Default. */
+#define RTIOW_SCHED_SORTED     2
 
 typedef struct rtiow_handle_s* rtiow_handle;
 
@@ -83,6 +88,7 @@ typedef struct {
     int32_t  scene_source;       /* RTIOW_SCENE_*                                          */
     int32_t  schedule;           /* RTIOW_SCHED_*                                          */
     int32_t  grid_blocks;        /* workgroups launched by the last render                 */
+    int32_t  phases;             /* 2 when RTIOW_SCHED_SORTED split the render, else 1     */
 } rtiow_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------

@@ -22,7 +22,7 @@ import numpy as np
 
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 SCENE_LDS, SCENE_SCALAR = 0, 1
-SCHED_STATIC, SCHED_PERSISTENT = 0, 1
+SCHED_STATIC, SCHED_PERSISTENT, SCHED_SORTED = 0, 1, 2
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIBDIR = os.path.join(_PKG, "lib")
@@ -60,7 +60,7 @@ class Stats(ctypes.Structure):
                 ("num_spheres", ctypes.c_int32), ("block_x", ctypes.c_int32), ("block_y", ctypes.c_int32),
                 ("vgprs", ctypes.c_int32), ("sgprs", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
                 ("scene_source", ctypes.c_int32),
-                ("schedule", ctypes.c_int32), ("grid_blocks", ctypes.c_int32)]
+                ("schedule", ctypes.c_int32), ("grid_blocks", ctypes.c_int32), ("phases", ctypes.c_int32)]
 
 
 # Every symbol include/rtiow.h declares (tests check that the built library exports them all).

@@ -28,6 +28,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -157,6 +158,17 @@ template <class T> struct RenderParams {
     unsigned long long* seg_counter;  // COUNT variant only: total hit_world calls (path segments)
     unsigned int* work_counter;       // SCHED_PERSISTENT: next unassigned pixel slot (zeroed per launch)
     int coop_offset;                  // SCHED_PERSISTENT: byte offset of the per-wave coop scratch in LDS
+    // SCHED_SORTED (two phases of the persistent kernel): sample range of this launch, the
+    // per-pixel state carried between the phases, and the cost-sorted hand-out order.
+    int s_begin, s_end;               // samples [s_begin, s_end) of every pixel
+    const uint32_t* __restrict__ rng_in;   // [6][npix] SoA state at sample s_begin
+    uint32_t* __restrict__ rng_out;   // phase A: state after sample s_end-1 (nullptr: final phase, pixel is stored)
+    const T* __restrict__ acc_in;     // [3][npix] colour sum of samples [0,s_begin) (nullptr: zero)
+    T* __restrict__ acc_out;          // phase A only
+    uint32_t* __restrict__ cost_out;  // phase A only: segments the pixel ran in this phase
+    const int* __restrict__ order;    // slot -> local pixel (or -1), nullptr: 8x8 tiles bottom-up
+    int total_slots;
+    int first_pools;                  // 1: wave w starts with pool w (the work counter then starts at the wave count)
     unsigned long long* timeline;     // COUNT variant, optional: per wave {t_start, t_exhausted, t_end, iters_normal, iters_coop, pixels, 0, 0}
 };
 
@@ -218,10 +230,33 @@ __device__ __forceinline__ void gen_primary(const RenderParams<T>& p, int i, int
     sky_uy = inv * D.y;
 }
 
+// raw hardware square root (v_sqrt_f32 / v_sqrt_f64, error <= 2^-22 relative): used ONLY inside the
+// conservative pre-test below, never for a value that reaches the image.
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double fast_sqrt(double x) { return __builtin_amdgcn_sqrt(x); }
+
 // Second half of hit_sphere (hittable.h:50-57) once the discriminant is known to be >= 0.
+//
+// Most spheres that get here are then rejected (behind the origin, or farther than the hit
+// already found), after an IEEE sqrt and up to two IEEE divisions (~56 instructions).  A cheap
+// pre-test drops a sphere ONLY when the exact code below provably would: all roots of one ray
+// share the divisor a > 0, so they order like their numerators n = h -+ sqrt(disc);
+//   (behind) n2 + e <  tmin*a*(1-2^-20)  =>  both exact roots <= tmin;
+//   (far)    n1 - e >  closest*a*(1+2^-20) =>  exact near root >= closest, hence the far one too;
+// with e = 2^-20 (|h| + sqrt) covering the raw sqrt's error (2^-22) and every rounding involved
+// (2^-23 each) four times over.  In doubt the exact code runs, so the result is unchanged.
 template <class T>
 __device__ __forceinline__ void finish_sphere_test(int s, T h, T disc, T a, T& closest, int& hit) {
     const T tmin = (T)0.001;
+    {
+        const T kappa = (T)9.5367431640625e-07;                        // 2^-20
+        const T sq_approx = fast_sqrt(disc);
+        const T e = kappa * (Real<T>::fabs(h) + sq_approx);
+        const T behind_bound = (tmin * a) * (T)0.99999904632568359375;  // tmin*a*(1-2^-20)
+        const T far_bound = (closest * a) * (T)1.00000095367431640625; // closest*a*(1+2^-20); inf while nothing is hit
+        if ((h + sq_approx) + e < behind_bound) return;
+        if ((h - sq_approx) - e > far_bound) return;
+    }
     const T sq = Real<T>::sqrt(disc);                               // :50
     T root = (h - sq) / a;                                          // :53
     bool ok = (tmin < root) && (root < closest);                    // :54
@@ -494,6 +529,20 @@ __device__ __forceinline__ int global_row(int jl, int strip_rows, int nranks, in
     return ((jl / strip_rows) * nranks + rank) * strip_rows + (jl % strip_rows);
 }
 
+// End of a pixel in one launch: the final phase writes the pixel
+// (camera.h:167-171); phase A of the sorted schedule parks the exact state instead.
+template <class T>
+__device__ __forceinline__ void finish_pixel(const RenderParams<T>& p, size_t lp, size_t npix, const PathState<T>& st, unsigned int cost) {
+    if (p.rng_out) {
+        p.rng_out[0 * npix + lp] = st.rs.v0; p.rng_out[1 * npix + lp] = st.rs.v1; p.rng_out[2 * npix + lp] = st.rs.v2;
+        p.rng_out[3 * npix + lp] = st.rs.v3; p.rng_out[4 * npix + lp] = st.rs.v4; p.rng_out[5 * npix + lp] = st.rs.d;
+        p.acc_out[0 * npix + lp] = st.acc.x; p.acc_out[1 * npix + lp] = st.acc.y; p.acc_out[2 * npix + lp] = st.acc.z;
+        p.cost_out[lp] = cost;
+    } else {
+        store_pixel(p, lp, st.acc);
+    }
+}
+
 // ---- SCHED_STATIC: the reference's launch geometry, one lane = one pixel of a T x T block
 // (camera.h:131-134), with the flattened sample/bounce loop.
 template <class T, int SRC, bool COUNT>
@@ -517,18 +566,20 @@ render_kernel(const RenderParams<T> p) {
     const int j = global_row(jl, p.strip_rows, p.nranks, p.rank);
     const size_t lp = (size_t)jl * p.W + i;
 
+    const size_t npix = (size_t)p.W * p.local_rows;
     PathState<T> st;
-    load_rng(p, lp, st.rs);
+    st.rs.v0 = p.rng_in[0 * npix + lp]; st.rs.v1 = p.rng_in[1 * npix + lp]; st.rs.v2 = p.rng_in[2 * npix + lp];   // camera.h:136
+    st.rs.v3 = p.rng_in[3 * npix + lp]; st.rs.v4 = p.rng_in[4 * npix + lp]; st.rs.d = p.rng_in[5 * npix + lp];
     st.acc = {0, 0, 0};
-    st.sample = 0; st.depth = 0;
-    unsigned int nseg = 0;
-    const int S = p.S;
+    st.sample = p.s_begin; st.depth = 0;          // this launch renders samples [s_begin, s_end)
+    unsigned int nseg = 0, cost = 0;
+    const int S = p.s_end;
     bool fresh = true;                            // the lane needs a primary ray (camera.h:141-155)
 
     while (st.sample < S) {
         if (fresh) { gen_primary(p, i, j, st.rs, st.O, st.D, st.sky_uy); st.atten = {1, 1, 1}; fresh = false; }
         V3<T> col;
-        if (COUNT && st.depth < p.B) ++nseg;
+        if (st.depth < p.B) { ++cost; if (COUNT) ++nseg; }
         if (segment_step<T, SRC>(p, lds_geom, st, col)) {
             st.acc = {st.acc.x + col.x, st.acc.y + col.y, st.acc.z + col.z};       // camera.h:160
             ++st.sample;
@@ -537,7 +588,7 @@ render_kernel(const RenderParams<T> p) {
         }
     }
     if (COUNT) atomicAdd(p.seg_counter, (unsigned long long)nseg);
-    store_pixel(p, lp, st.acc);
+    finish_pixel(p, lp, npix, st, cost);
 }
 
 // ---- SCHED_PERSISTENT: lanes are not bound to pixels.  Each wave keeps a pool of 64 pixel
@@ -556,18 +607,24 @@ render_persistent_kernel(const RenderParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     CoopSlot<T>* coop_slots = reinterpret_cast<CoopSlot<T>*>(smem_raw + p.coop_offset) + (threadIdx.x >> 6) * 64;
     const int tiles_x = (p.W + 7) >> 3, tiles_y = (p.local_rows + 7) >> 3;
-    const int total_slots = tiles_x * tiles_y * POOL;
-    const int S = p.S;
+    const int total_slots = p.total_slots;
+    const int S = p.s_end;                       // this launch renders samples [p.s_begin, p.s_end)
+    const size_t npix = (size_t)p.W * p.local_rows;
 
     PathState<T> st;
     st.acc = {0, 0, 0};
     st.sample = 0; st.depth = 0;
+    unsigned int cost = 0;                       // segments of the lane's current pixel in this launch
     bool alive = false, fresh = false;
     int i = 0, j = 0;
     size_t lp = 0;
     unsigned int nseg = 0;
     int pool_next = 0, pool_end = 0;             // wave-uniform
     bool exhausted = false;                      // wave-uniform
+    // p.first_pools: wave w takes pool w first and the counter starts behind them.  Workgroups are
+    // dispatched in blockIdx order and the SIMD arbiter favours older waves, so this puts the
+    // heaviest block of the cost-sorted order on the waves that will run fastest.
+    int first_pool = p.first_pools ? ((int)blockIdx.x * (int)((blockDim.x + 63) >> 6) + (int)(threadIdx.x >> 6)) * POOL : -1;
     unsigned long long t_start = 0, t_exh = 0;
     unsigned int it_normal = 0, it_coop = 0, n_pixels = 0;
     if (COUNT) t_start = __builtin_amdgcn_s_memrealtime();
@@ -582,8 +639,13 @@ render_persistent_kernel(const RenderParams<T> p) {
                 if (m == 0) break;
                 if (pool_next >= pool_end) {     // refill the wave's pool: one atomic per 64 pixels
                     int base = 0;
-                    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) base = (int)atomicAdd(p.work_counter, (unsigned)POOL);
-                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (first_pool >= 0) {       // the first pool follows dispatch order (= wave age), see launch_render
+                        base = first_pool;
+                        first_pool = -1;
+                    } else {
+                        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) base = (int)atomicAdd(p.work_counter, (unsigned)POOL);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                    }
                     if (base >= total_slots) { exhausted = true; if (COUNT) t_exh = __builtin_amdgcn_s_memrealtime(); break; }
                     pool_next = base; pool_end = base + POOL;
                 }
@@ -594,20 +656,33 @@ render_persistent_kernel(const RenderParams<T> p) {
                 const int slot = pool_next + rank;
                 pool_next += wanted < avail ? wanted : avail;
                 if (take) {
-                    const int t = slot >> 6, within = slot & 63;
-                    const int ty = tiles_y - 1 - t / tiles_x, tx = t % tiles_x;
-                    i = tx * 8 + (within & 7);
-                    const int jl = ty * 8 + (within >> 3);
-                    if (i < p.W && jl < p.local_rows) {          // padded slots of ragged tiles are skipped
+                    int jl;
+                    bool valid;
+                    if (p.order) {                               // cost-sorted hand-out (phase B)
+                        const int px = p.order[slot];
+                        valid = px >= 0;
+                        jl = valid ? px / p.W : 0;
+                        i = valid ? px - jl * p.W : 0;
+                    } else {                                     // 8x8 tiles, bottom-up
+                        const int t = slot >> 6, within = slot & 63;
+                        const int ty = tiles_y - 1 - t / tiles_x, tx = t % tiles_x;
+                        i = tx * 8 + (within & 7);
+                        jl = ty * 8 + (within >> 3);
+                        valid = i < p.W && jl < p.local_rows;    // padded slots of ragged tiles are skipped
+                    }
+                    if (valid) {
                         want = false;
                         j = global_row(jl, p.strip_rows, p.nranks, p.rank);
                         lp = (size_t)jl * p.W + i;
-                        load_rng(p, lp, st.rs);
-                        st.acc = {0, 0, 0};
-                        st.sample = 0; st.depth = 0;
+                        st.rs.v0 = p.rng_in[0 * npix + lp]; st.rs.v1 = p.rng_in[1 * npix + lp]; st.rs.v2 = p.rng_in[2 * npix + lp];
+                        st.rs.v3 = p.rng_in[3 * npix + lp]; st.rs.v4 = p.rng_in[4 * npix + lp]; st.rs.d = p.rng_in[5 * npix + lp];
+                        if (p.acc_in) st.acc = {p.acc_in[0 * npix + lp], p.acc_in[1 * npix + lp], p.acc_in[2 * npix + lp]};
+                        else st.acc = {0, 0, 0};
+                        st.sample = p.s_begin; st.depth = 0;
+                        cost = 0;
                         if (COUNT) ++n_pixels;
-                        if (S > 0) { alive = true; fresh = true; }
-                        else { store_pixel(p, lp, st.acc); want = true; }   // zero samples: black pixel
+                        if (p.s_begin < S) { alive = true; fresh = true; }
+                        else { finish_pixel(p, lp, npix, st, cost); want = true; }   // nothing to render in this launch
                     }
                 }
             }
@@ -630,13 +705,13 @@ render_persistent_kernel(const RenderParams<T> p) {
                 hit_world_coop<T, SRC>(p, lds_geom, coop_slots, need_hit, hit_mask, __builtin_popcountll(hit_mask), wave_lanes, st.O, st.D, a, closest, hit);
             }
             if (alive) {
-                if (COUNT && need_hit) ++nseg;
+                if (need_hit) { ++cost; if (COUNT) ++nseg; }
                 terminated = need_hit ? shade_step<T>(p, st, closest, hit, col) : true;   // camera.h:127 at the depth limit
             }
         } else {
             if (COUNT) ++it_normal;
             if (alive) {
-                if (COUNT && st.depth < p.B) ++nseg;
+                if (st.depth < p.B) { ++cost; if (COUNT) ++nseg; }
                 terminated = segment_step<T, SRC>(p, lds_geom, st, col);
             }
         }
@@ -645,7 +720,7 @@ render_persistent_kernel(const RenderParams<T> p) {
             ++st.sample;
             st.depth = 0;
             if (st.sample < S) fresh = true;
-            else { store_pixel(p, lp, st.acc); alive = false; }
+            else { finish_pixel(p, lp, npix, st, cost); alive = false; }
         }
     }
     if (COUNT) {
@@ -673,6 +748,84 @@ __global__ void debug_ops_kernel(int op, size_t n, const T* a, const T* b, const
         case 3: { uint32_t x; memcpy(&x, &a[k], 4); out[k] = Real<T>::from_u32(x); break; }
         case 4: out[k] = a[k] * b[k] + c[k]; break;
         default: out[k] = 0;
+    }
+}
+
+// ---- SCHED_SORTED: counting sort of the pixels by the cost measured in phase A, heavy first,
+// dealt into balanced pools.  Sorted rank r -> slot: ranks are cut into blocks of
+// `pools_per_block` pools (the resident waves); inside a block consecutive ranks go to
+// consecutive pools, so every pool of a block gets the same mix of costs and the blocks run
+// from the heaviest pixels to the lightest.
+constexpr int COST_BINS = 1024;
+
+__global__ void __launch_bounds__(256) cost_hist_kernel(const uint32_t* __restrict__ cost, int npix, unsigned* __restrict__ hist) {
+    __shared__ unsigned local[COST_BINS];
+    for (int b = threadIdx.x; b < COST_BINS; b += blockDim.x) local[b] = 0;
+    __syncthreads();
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < npix; k += gridDim.x * blockDim.x) {
+        const unsigned c = cost[k];
+        atomicAdd(&local[c < COST_BINS ? c : COST_BINS - 1], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < COST_BINS; b += blockDim.x) if (local[b]) atomicAdd(&hist[b], local[b]);
+}
+
+// start[b] = number of pixels with a HIGHER bin (heavy first); also zeroes the fill counters.
+__global__ void __launch_bounds__(COST_BINS) cost_scan_kernel(const unsigned* __restrict__ hist, unsigned* __restrict__ start, unsigned* __restrict__ fill) {
+    __shared__ unsigned tmp[COST_BINS];
+    const int b = threadIdx.x;
+    tmp[b] = hist[COST_BINS - 1 - b];            // reversed: index 0 = heaviest bin
+    __syncthreads();
+    for (int off = 1; off < COST_BINS; off <<= 1) {
+        const unsigned v = b >= off ? tmp[b - off] : 0;
+        __syncthreads();
+        tmp[b] += v;
+        __syncthreads();
+    }
+    start[COST_BINS - 1 - b] = tmp[b] - hist[COST_BINS - 1 - b];   // exclusive
+    fill[b] = 0;
+}
+
+// Each 1024-thread block ranks 4096 pixels: a block-private histogram in LDS, ONE global atomic per
+// non-empty bin to reserve the block's range of ranks, then LDS atomics for the rank inside it
+// (2 M contended global atomics on ~20 hot bins took 17.8 ms; this takes microseconds).
+constexpr int SCATTER_PER_THREAD = 4;
+__global__ void __launch_bounds__(1024) cost_scatter_kernel(const uint32_t* __restrict__ cost, int npix, const unsigned* __restrict__ start,
+                                                            unsigned* __restrict__ fill, int* __restrict__ order, int pools_per_block, int total_pools) {
+    __shared__ unsigned local[COST_BINS];        // block histogram, then the running rank inside the reserved range
+    __shared__ unsigned base[COST_BINS];
+    for (int b = threadIdx.x; b < COST_BINS; b += blockDim.x) local[b] = 0;
+    __syncthreads();
+    const int first = blockIdx.x * blockDim.x * SCATTER_PER_THREAD;
+    int bins[SCATTER_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < SCATTER_PER_THREAD; ++u) {
+        const int k = first + u * (int)blockDim.x + (int)threadIdx.x;
+        bins[u] = -1;
+        if (k < npix) {
+            const unsigned c = cost[k];
+            bins[u] = c < COST_BINS ? (int)c : COST_BINS - 1;
+            atomicAdd(&local[bins[u]], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < COST_BINS; b += blockDim.x) {
+        const unsigned n = local[b];
+        base[b] = n ? start[b] + atomicAdd(&fill[b], n) : 0;
+        local[b] = 0;
+    }
+    __syncthreads();
+    const int per_block = pools_per_block * POOL;
+#pragma unroll
+    for (int u = 0; u < SCATTER_PER_THREAD; ++u) {
+        if (bins[u] < 0) continue;
+        const int k = first + u * (int)blockDim.x + (int)threadIdx.x;
+        const int r = (int)(base[bins[u]] + atomicAdd(&local[bins[u]], 1u));   // sorted rank (order inside a bin is immaterial)
+        const int blk = r / per_block, q = r - blk * per_block;
+        const int pools_here = (blk + 1) * pools_per_block <= total_pools ? pools_per_block : total_pools - blk * pools_per_block;
+        const int pool = blk * pools_per_block + q % pools_here;
+        const int lane_slot = q / pools_here;
+        order[pool * POOL + lane_slot] = k;
     }
 }
 
@@ -742,7 +895,12 @@ struct rtiow_handle_s {
     bool fb_external = false;
     // knobs / stats
     int scene_source = RTIOW_SCENE_LDS;
-    int schedule = RTIOW_SCHED_PERSISTENT;
+    int schedule = RTIOW_SCHED_SORTED;
+    uint32_t* rng_mid = nullptr; size_t rng_mid_bytes = 0;      // SCHED_SORTED: state parked between the phases
+    void* acc_mid = nullptr; size_t acc_mid_bytes = 0;
+    uint32_t* cost = nullptr; size_t cost_bytes = 0;
+    int* order = nullptr; size_t order_bytes = 0;
+    unsigned* sort_scratch = nullptr; size_t sort_scratch_bytes = 0;
     int waves_per_simd = 0;
     int num_cus = 256;
     int last_count_blocks = 0;
@@ -865,11 +1023,21 @@ RenderFn<T> pick_kernel(bool persistent, bool lds, bool count) {
     return count ? pick_sched<T, RTIOW_SCENE_SCALAR, true>(persistent) : pick_sched<T, RTIOW_SCENE_SCALAR, false>(persistent);
 }
 
+// (Re)allocates a device buffer kept in the handle when it is too small.
+template <class P>
+int ensure_buffer(rtiow_handle_s* h, P** ptr, size_t* have, size_t need) {
+    if (*ptr && *have >= need) return 0;
+    if (*ptr) { HIP_TRY(h, hipFree(*ptr)); *ptr = nullptr; *have = 0; }
+    HIP_TRY(h, hipMalloc((void**)ptr, need));
+    *have = need;
+    return 0;
+}
+
 template <class T, class CAM>
 int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_tiles, unsigned long long* seg_counter = nullptr) {
     RenderParams<T> p = make_params<T>(h, cam);
     p.bx = bx; p.by = by; p.wave_tiles = wave_tiles; p.seg_counter = seg_counter;
-    const bool persistent = h->schedule == RTIOW_SCHED_PERSISTENT;
+    const bool persistent = h->schedule != RTIOW_SCHED_STATIC;
     const int threads = bx * by;
     size_t lds = h->scene_source == RTIOW_SCENE_LDS ? sizeof(T) * 4 * (size_t)h->n_padded : 0;
     p.timeline = seg_counter ? h->timeline : nullptr;
@@ -881,10 +1049,10 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     hipFuncAttributes fa{};
     HIP_TRY(h, hipFuncGetAttributes(&fa, (const void*)k));
     dim3 grid, block(threads);
+    int phases = 1;
     if (persistent) {
-        if (!h->work_counter) HIP_TRY(h, hipMalloc((void**)&h->work_counter, sizeof(unsigned int)));
-        HIP_TRY(h, hipMemsetAsync(h->work_counter, 0, sizeof(unsigned int), h->stream));
-        p.work_counter = h->work_counter;
+        if (!h->work_counter) HIP_TRY(h, hipMalloc((void**)&h->work_counter, 2 * sizeof(unsigned int)));
+        HIP_TRY(h, hipMemsetAsync(h->work_counter, 0, 2 * sizeof(unsigned int), h->stream));
         int per_cu = 0;
         HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, threads, lds));
         if (per_cu < 1) per_cu = 1;
@@ -893,13 +1061,68 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             const int cap = (h->waves_per_simd * 4 + waves_per_block - 1) / waves_per_block;
             if (cap < per_cu) per_cu = cap;
         }
-        const long long slots = (long long)((p.W + 7) / 8) * ((h->local_rows + 7) / 8) * POOL;
+        const long long tile_slots = (long long)((p.W + 7) / 8) * ((h->local_rows + 7) / 8) * POOL;
         long long blocks = (long long)h->num_cus * per_cu;
-        const long long useful = (slots + (long long)waves_per_block * POOL - 1) / ((long long)waves_per_block * POOL);
+        const long long useful = (tile_slots + (long long)waves_per_block * POOL - 1) / ((long long)waves_per_block * POOL);
         if (blocks > useful) blocks = useful;               // never more waves than 64-pixel pools
         grid = dim3((unsigned)blocks);
+
+        const int npix = p.W * h->local_rows;
+        const int S = p.S;
+        // phase A length: enough samples to rank the pixels, a small share of the frame
+        const int SA = S >= 64 ? 4 : (S >= 24 ? 2 : 0);
+        p.work_counter = h->work_counter;
+        p.s_begin = 0; p.s_end = S; p.rng_in = h->rng; p.rng_out = nullptr; p.acc_in = nullptr; p.acc_out = nullptr;
+        p.cost_out = nullptr; p.order = nullptr; p.total_slots = (int)tile_slots; p.first_pools = 0;
+        if (h->schedule == RTIOW_SCHED_SORTED && SA > 0 && npix >= 4096) {
+            phases = 2;
+            const int total_pools = (npix + POOL - 1) / POOL;
+            int rc;
+            if ((rc = ensure_buffer(h, &h->rng_mid, &h->rng_mid_bytes, (size_t)npix * 6 * sizeof(uint32_t)))) return rc;
+            if ((rc = ensure_buffer(h, (unsigned char**)&h->acc_mid, &h->acc_mid_bytes, (size_t)npix * 3 * sizeof(T)))) return rc;
+            if ((rc = ensure_buffer(h, &h->cost, &h->cost_bytes, (size_t)npix * sizeof(uint32_t)))) return rc;
+            if ((rc = ensure_buffer(h, &h->order, &h->order_bytes, (size_t)total_pools * POOL * sizeof(int)))) return rc;
+            if ((rc = ensure_buffer(h, &h->sort_scratch, &h->sort_scratch_bytes, (size_t)3 * COST_BINS * sizeof(unsigned)))) return rc;
+            // ---- phase A: samples [0, SA) with the STATIC kernel (one lane per pixel of an 8x8
+            // tile, coalesced state traffic, no hand-out machinery); state parked per pixel.
+            RenderParams<T> pa = p;
+            pa.s_end = SA; pa.rng_out = h->rng_mid; pa.acc_out = (T*)h->acc_mid; pa.cost_out = h->cost;
+            pa.bx = 16; pa.by = 16; pa.wave_tiles = 1;
+            const size_t lds_a = h->scene_source == RTIOW_SCENE_LDS ? sizeof(T) * 4 * (size_t)h->n_padded : 0;
+            RenderFn<T> ka = pick_kernel<T>(false, h->scene_source == RTIOW_SCENE_LDS, seg_counter != nullptr);
+            if (lds_a > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+            hipLaunchKernelGGL(ka, dim3((p.W + 15) / 16, (h->local_rows + 15) / 16), dim3(256), lds_a, h->stream, pa);
+            HIP_TRY(h, hipGetLastError());
+            // ---- rank the pixels by measured cost, heavy first, dealt into balanced pools.
+            // Blocks of the order are one "age class" of resident waves wide (see first_pools).
+            unsigned* hist = h->sort_scratch; unsigned* start = hist + COST_BINS; unsigned* fill = start + COST_BINS;
+            HIP_TRY(h, hipMemsetAsync(hist, 0, COST_BINS * sizeof(unsigned), h->stream));
+            HIP_TRY(h, hipMemsetAsync(h->order, 0xff, (size_t)total_pools * POOL * sizeof(int), h->stream));
+            const int sort_blocks = (npix + 255) / 256;
+            hipLaunchKernelGGL(cost_hist_kernel, dim3(sort_blocks < 1024 ? sort_blocks : 1024), dim3(256), 0, h->stream, h->cost, npix, hist);
+            hipLaunchKernelGGL(cost_scan_kernel, dim3(1), dim3(COST_BINS), 0, h->stream, hist, start, fill);
+            const int resident_waves = (int)blocks * waves_per_block;
+            const int age_classes = (int)((blocks + h->num_cus - 1) / h->num_cus);
+            int pools_per_block = (resident_waves + age_classes - 1) / age_classes;
+            if (pools_per_block > total_pools) pools_per_block = total_pools;
+            if (const char* e = std::getenv("RTIOW_DEBUG_POOLS_PER_BLOCK")) { const int v = std::atoi(e); if (v >= 1) pools_per_block = v < total_pools ? v : total_pools; }
+            const int scatter_blocks = (npix + 1024 * SCATTER_PER_THREAD - 1) / (1024 * SCATTER_PER_THREAD);
+            hipLaunchKernelGGL(cost_scatter_kernel, dim3(scatter_blocks), dim3(1024), 0, h->stream, h->cost, npix, start, fill, h->order,
+                               pools_per_block, total_pools);
+            HIP_TRY(h, hipGetLastError());
+            // ---- phase B: samples [SA, S) in that order
+            p.s_begin = SA; p.rng_in = h->rng_mid; p.acc_in = (const T*)h->acc_mid; p.order = h->order;
+            p.total_slots = total_pools * POOL;
+            if (std::getenv("RTIOW_DEBUG_NO_SORT")) { p.order = nullptr; p.total_slots = (int)tile_slots; }
+            p.work_counter = h->work_counter + 1;
+            p.first_pools = std::getenv("RTIOW_DEBUG_NO_FIRST") ? 0 : 1;
+            const unsigned counter_start = p.first_pools ? (unsigned)resident_waves * POOL : 0u;
+            HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)(h->work_counter + 1), (int)counter_start, 1, h->stream));
+        }
     } else {
         grid = dim3((p.W + bx - 1) / bx, (h->local_rows + by - 1) / by);
+        p.s_begin = 0; p.s_end = p.S; p.rng_in = h->rng; p.rng_out = nullptr; p.acc_in = nullptr; p.acc_out = nullptr;
+        p.cost_out = nullptr; p.order = nullptr; p.total_slots = 0; p.first_pools = 0; p.work_counter = nullptr;
     }
     hipLaunchKernelGGL(k, grid, block, lds, h->stream, p);
     HIP_TRY(h, hipGetLastError());
@@ -912,6 +1135,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         h->stats.scene_source = h->scene_source;
         h->stats.schedule = h->schedule;
         h->stats.grid_blocks = (int)(grid.x * grid.y);
+        h->stats.phases = phases;
     }
     return 0;
 }
@@ -955,7 +1179,8 @@ int rtiow_destroy(rtiow_handle h) {
     if (!h) return RTIOW_E_BADARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->geom_a, h->geom_b, h->mat_a, h->mat_b, h->mat_type, h->rng, h->jump, h->work_counter, h->fb_external ? nullptr : h->fb};
+    void* bufs[] = {h->geom_a, h->geom_b, h->mat_a, h->mat_b, h->mat_type, h->rng, h->jump, h->work_counter, h->rng_mid, h->acc_mid,
+                    h->cost, h->order, h->sort_scratch, h->fb_external ? nullptr : h->fb};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1154,7 +1379,7 @@ int rtiow_set_scene_source(rtiow_handle h, int scene_source) {
 
 int rtiow_set_schedule(rtiow_handle h, int schedule, int waves_per_simd) {
     if (!h) return RTIOW_E_BADARG;
-    if ((schedule != RTIOW_SCHED_STATIC && schedule != RTIOW_SCHED_PERSISTENT) || waves_per_simd < 0 || waves_per_simd > 8)
+    if ((schedule != RTIOW_SCHED_STATIC && schedule != RTIOW_SCHED_PERSISTENT && schedule != RTIOW_SCHED_SORTED) || waves_per_simd < 0 || waves_per_simd > 8)
         return fail_arg(h, RTIOW_E_BADARG, "rtiow_set_schedule: unknown schedule or waves_per_simd outside 0..8");
     h->schedule = schedule; h->waves_per_simd = waves_per_simd;
     return 0;
@@ -1188,7 +1413,7 @@ int rtiow_debug_read_rng(rtiow_handle h, uint32_t* host_states, size_t count_wor
 
 int rtiow_debug_timeline(rtiow_handle h, int threads_per_block_row, uint64_t* out_words, size_t cap_words, int* waves) {
     if (!h || !out_words || !waves) return RTIOW_E_BADARG;
-    if (h->schedule != RTIOW_SCHED_PERSISTENT) return fail_arg(h, RTIOW_E_STATE, "rtiow_debug_timeline needs RTIOW_SCHED_PERSISTENT");
+    if (h->schedule == RTIOW_SCHED_STATIC) return fail_arg(h, RTIOW_E_STATE, "rtiow_debug_timeline needs a persistent schedule");
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t max_waves = 16384;
     HIP_TRY(h, hipMalloc((void**)&h->timeline, max_waves * 8 * sizeof(unsigned long long)));

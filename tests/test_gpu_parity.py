@@ -22,7 +22,7 @@ def rt(native):
     return native
 
 
-def _render(rt, prec, scene_id, W, H, S, B, threads=8, source=0, shard=None, seed=1227, sched=1, wps=0):
+def _render(rt, prec, scene_id, W, H, S, B, threads=8, source=0, shard=None, seed=1227, sched=2, wps=0):
     sc = rt.build_scene(scene_id, prec)
     with rt.Renderer(0, prec) as r:
         r.set_camera(rt.camera(prec, W, H, S, B))
@@ -125,10 +125,14 @@ def test_render_matches_committed_golden_images(rt, golden_dir):
     (32, 3, 7, 3, 1, 1),
     (32, 3, 64, 8, 7, 0),           # zero bounces: ray_color returns black at once
     (64, 2, 33, 9, 2, 3),
+    (32, 3, 128, 72, 64, 12),       # two-phase sorted schedule: 4 ranking samples + 60
+    (64, 3, 96, 48, 24, 8),         # two-phase, 2 ranking samples, fp64 state carried between phases
+    (32, 1, 96, 64, 24, 50),
+    (32, 3, 131, 67, 70, 6),        # two-phase with ragged pools (npix not a multiple of 64)
 ])
 def test_render_bit_exact_vs_oracle(rt, oracle, prec, scene_id, W, H, S, B):
     want, stats = _oracle(oracle, rt, prec, scene_id, W, H, S, B)
-    for sched in (rt.SCHED_PERSISTENT, rt.SCHED_STATIC):
+    for sched in (rt.SCHED_SORTED, rt.SCHED_PERSISTENT, rt.SCHED_STATIC):
         got = _render(rt, prec, scene_id, W, H, S, B, sched=sched)
         assert _same_bits(got, want), sched
     assert np.isfinite(got).all()
@@ -138,7 +142,7 @@ def test_block_shapes_and_scene_sources_give_the_same_image(rt, oracle):
     want, _ = _oracle(oracle, rt, 32, 3, 100, 60, 3, 12)
     for threads in (0, 1, 4, 8, 16, 32):
         for source in (rt.SCENE_LDS, rt.SCENE_SCALAR):
-            for sched, wps in ((rt.SCHED_PERSISTENT, 0), (rt.SCHED_PERSISTENT, 1), (rt.SCHED_STATIC, 0)):
+            for sched, wps in ((rt.SCHED_SORTED, 0), (rt.SCHED_PERSISTENT, 0), (rt.SCHED_PERSISTENT, 1), (rt.SCHED_STATIC, 0)):
                 got = _render(rt, 32, 3, 100, 60, 3, 12, threads, source, sched=sched, wps=wps)
                 assert _same_bits(got, want), (threads, source, sched, wps)
     want64, _ = _oracle(oracle, rt, 64, 3, 50, 30, 2, 12)
@@ -147,7 +151,7 @@ def test_block_shapes_and_scene_sources_give_the_same_image(rt, oracle):
 
 
 def test_segment_count_matches_oracle(rt, oracle):
-    for prec, sid, W, H, S, B in [(32, 3, 96, 56, 5, 25), (32, 1, 64, 40, 3, 50), (64, 2, 40, 24, 4, 10)]:
+    for prec, sid, W, H, S, B in [(32, 3, 96, 56, 5, 25), (32, 1, 64, 40, 3, 50), (64, 2, 40, 24, 4, 10), (32, 3, 128, 64, 30, 25)]:
         want, stats = _oracle(oracle, rt, prec, sid, W, H, S, B)
         with rt.Renderer(0, prec) as r:
             r.set_camera(rt.camera(prec, W, H, S, B)); r.set_scene(rt.build_scene(sid, prec)); r.init_rng(1227)
