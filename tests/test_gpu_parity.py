@@ -232,6 +232,24 @@ def test_executable_is_a_drop_in(rt, oracle, tmp_path):
     assert os.path.exists(str(tmp_path / "global_double_scene3_320x192_1samples_2bounces_8threadsPerBlockRow.ppm"))
 
 
+def test_benchmark_harness_csv_round_trip(rt, tmp_path):
+    """tools/hip_benchmark.sh (global_float_benchmark.sh's loop) -> reference CSV schema -> bin/csv_avg."""
+    from tests.conftest import ROOT
+    csv = str(tmp_path / "bench.csv")
+    env = dict(os.environ, SCENE_IDS="3", WIDTHS="64 96", HEIGHTS="40 56", SAMPLES="2", BOUNCES="5", THREADS="8 16", RUNS="2")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "hip_benchmark.sh"), "float", csv], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = open(csv).read().splitlines()
+    assert lines[0] == "scene_id,width,height,samples,bounces,threads,run,render_only_time_ms,end_to_end_time_ms"
+    assert len(lines) == 1 + 2 * 2 * 2
+    for line in lines[1:]:
+        assert re.fullmatch(r"3,(64,40|96,56),2,5,(8|16),[12], *\d+\.\d{8}, *\d+\.\d{8}", line), line
+    avg = str(tmp_path / "avg.csv")
+    exe = os.path.join(os.path.dirname(rt.lib_paths()["hip"]), "..", "bin", "csv_avg")
+    assert subprocess.run([exe, csv, avg], capture_output=True).returncode == 0
+    assert len(open(avg).read().splitlines()) == 1 + 4
+
+
 def test_full_size_properties(rt, oracle):
     """BASELINE headline config (scene 3, 1920x1080, 100 spp, 50 bounces): too big for the
     oracle in full, so: (1) run-to-run determinism, (2) 8-way sharded == whole image,
