@@ -146,10 +146,11 @@ template <class T> struct RenderParams {
     V3<T> ddu, ddv;
     int n, n_padded;                  // spheres, and the table length padded to a multiple of 4
     const T* __restrict__ geom_a;     // [n_padded][4] cx,cy,cz,r*r (sphere loop; padding never hits)
-    const T* __restrict__ geom_b;     // [n][4] cx,cy,cz,1/r       (hit completion)
-    const T* __restrict__ mat_a;      // [n][4] albedo rgb, fuzz
-    const T* __restrict__ mat_b;      // [n][2] ri, 1/ri
-    const int* __restrict__ mat_type; // [n]
+    // everything the shade step needs about the sphere that was hit, 12 T per sphere:
+    // {cx,cy,cz,1/r | albedo r,g,b,fuzz | eta, 1/eta, material type, 0}
+    const T* __restrict__ shade_tbl;
+    int shade_in_lds;                 // 1: the table is staged behind the loop table in LDS (shade_offset bytes)
+    int shade_offset;
     const uint32_t* __restrict__ rng; // [6][npix_local] SoA
     T* __restrict__ fb;               // [local_rows][W][3]
     int local_rows, rank, nranks, strip_rows;
@@ -369,7 +370,7 @@ template <class T> struct PathState {
 // (camera.h:120-124), else hit record + scatter (camera.h:88-117).  Returns true when the
 // path ended; `col` is then its colour.
 template <class T>
-__device__ __forceinline__ bool shade_step(const RenderParams<T>& p, PathState<T>& st, T closest, int hit, V3<T>& col) {
+__device__ __forceinline__ bool shade_step(const RenderParams<T>& p, const T* lds_shade, PathState<T>& st, T closest, int hit, V3<T>& col) {
     col = {0, 0, 0};
     const V3<T> O = st.O, D = st.D;
     if (hit < 0) {
@@ -381,22 +382,29 @@ __device__ __forceinline__ bool shade_step(const RenderParams<T>& p, PathState<T
         return true;
     }
     // ------------ complete the hit record (hittable.h:59-63, :21-26)
-    const T* gb = p.geom_b + 4 * (size_t)hit;
-    const V3<T> C = {gb[0], gb[1], gb[2]};
-    const T inv_r = gb[3];
+    // one 12-word record per sphere; LDS copy when it fits (no global-load latency on the
+    // critical path of the drain tail), else through L1/L2
+    T rec[12];
+    if (p.shade_in_lds) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) rec[k] = lds_shade[12 * hit + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) rec[k] = p.shade_tbl[12 * (size_t)hit + k];
+    }
+    const V3<T> C = {rec[0], rec[1], rec[2]};
+    const T inv_r = rec[3];
     const V3<T> P = madd3(closest, D, O);
     const V3<T> outward = {inv_r * (P.x - C.x), inv_r * (P.y - C.y), inv_r * (P.z - C.z)};
     const bool front = dot3(D, outward) < (T)0;
     const V3<T> nrm = front ? outward : V3<T>{-outward.x, -outward.y, -outward.z};
-    const int mtype = p.mat_type[hit];
-    const T* ma = p.mat_a + 4 * (size_t)hit;
+    const int mtype = (int)rec[10];
     V3<T> nd;
-    V3<T> att = {ma[0], ma[1], ma[2]};
+    V3<T> att = {rec[4], rec[5], rec[6]};
     bool ok = true;
     if (mtype == RTIOW_DIELECTRIC) {                                     // material.h:68-89
         att = {1, 1, 1};
-        const T* mb = p.mat_b + 2 * (size_t)hit;
-        const T ri = front ? mb[1] : mb[0];
+        const T ri = front ? rec[9] : rec[8];
         const V3<T> ud = unit3(D);
         const T cos_theta = Real<T>::fmin(-dot3(ud, nrm), (T)1);
         const T sin_theta = Real<T>::sqrt(RT_FMA(-cos_theta, cos_theta, (T)1));
@@ -425,7 +433,7 @@ __device__ __forceinline__ bool shade_step(const RenderParams<T>& p, PathState<T
             if (Real<T>::fabs(nd.x) < e && Real<T>::fabs(nd.y) < e && Real<T>::fabs(nd.z) < e) nd = nrm;
         } else {                                                         // material.h:51-59
             const V3<T> ur = unit3(reflect3(D, nrm));
-            nd = madd3(ma[3], ruv, ur);
+            nd = madd3(rec[7], ruv, ur);
             ok = dot3(nd, nrm) > (T)0;
         }
     }
@@ -438,14 +446,14 @@ __device__ __forceinline__ bool shade_step(const RenderParams<T>& p, PathState<T
 
 // One path segment (one trip of the loop at camera.h:84) done by the lane alone.
 template <class T, int SRC>
-__device__ __forceinline__ bool segment_step(const RenderParams<T>& p, const T* lds_geom, PathState<T>& st, V3<T>& col) {
+__device__ __forceinline__ bool segment_step(const RenderParams<T>& p, const T* lds_geom, const T* lds_shade, PathState<T>& st, V3<T>& col) {
     if (st.depth >= p.B) { col = {0, 0, 0}; return true; }   // camera.h:127 (also B <= 0)
     // ---------------- hit_world (hittable.h:80-98), nearest (t, index) only
     T closest = __builtin_huge_val();
     int hit = -1;
     const T a = dot3(st.D, st.D);                 // hittable.h:43, ray-invariant
     hit_world_direct<T, SRC>(p, lds_geom, st.O, st.D, a, closest, hit);
-    return shade_step<T>(p, st, closest, hit, col);
+    return shade_step<T>(p, lds_shade, st, closest, hit, col);
 }
 
 // ---- cooperative hit_world for the drain tail of the persistent kernel.
@@ -517,9 +525,15 @@ template <class T, int SRC>
 __device__ __forceinline__ T* stage_scene(const RenderParams<T>& p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* lds_geom = reinterpret_cast<T*>(smem_raw);
-    if (SRC == RTIOW_SCENE_LDS) {
-        // Stage {cx,cy,cz,r^2} for all spheres: coalesced global reads, one pass.
-        for (int k = threadIdx.x; k < p.n_padded * 4; k += blockDim.x) lds_geom[k] = p.geom_a[k];
+    if (SRC == RTIOW_SCENE_LDS || p.shade_in_lds) {
+        // Stage the loop table {cx,cy,cz,r^2} (and the shade records when they fit): coalesced
+        // global reads, one pass.
+        if (SRC == RTIOW_SCENE_LDS)
+            for (int k = threadIdx.x; k < p.n_padded * 4; k += blockDim.x) lds_geom[k] = p.geom_a[k];
+        if (p.shade_in_lds) {
+            T* lds_shade = reinterpret_cast<T*>(smem_raw + p.shade_offset);
+            for (int k = threadIdx.x; k < p.n * 12; k += blockDim.x) lds_shade[k] = p.shade_tbl[k];
+        }
         __syncthreads();
     }
     return lds_geom;
@@ -549,6 +563,8 @@ template <class T, int SRC, bool COUNT>
 __global__ void __launch_bounds__(1024)
 render_kernel(const RenderParams<T> p) {
     const T* lds_geom = stage_scene<T, SRC>(p);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const T* lds_shade = reinterpret_cast<const T*>(smem_raw + p.shade_offset);
     const int tid = threadIdx.x;
     int tx, ty;
     if (p.wave_tiles) {
@@ -580,7 +596,7 @@ render_kernel(const RenderParams<T> p) {
         if (fresh) { gen_primary(p, i, j, st.rs, st.O, st.D, st.sky_uy); st.atten = {1, 1, 1}; fresh = false; }
         V3<T> col;
         if (st.depth < p.B) { ++cost; if (COUNT) ++nseg; }
-        if (segment_step<T, SRC>(p, lds_geom, st, col)) {
+        if (segment_step<T, SRC>(p, lds_geom, lds_shade, st, col)) {
             st.acc = {st.acc.x + col.x, st.acc.y + col.y, st.acc.z + col.z};       // camera.h:160
             ++st.sample;
             st.depth = 0;
@@ -603,8 +619,9 @@ template <class T, int SRC, bool COUNT>
 __global__ void __launch_bounds__(1024)
 render_persistent_kernel(const RenderParams<T> p) {
     const T* lds_geom = stage_scene<T, SRC>(p);
-    // per-wave scratch for hit_world_coop, behind the staged geometry
+    // per-wave scratch for hit_world_coop, behind the staged tables
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const T* lds_shade = reinterpret_cast<const T*>(smem_raw + p.shade_offset);
     CoopSlot<T>* coop_slots = reinterpret_cast<CoopSlot<T>*>(smem_raw + p.coop_offset) + (threadIdx.x >> 6) * 64;
     const int tiles_x = (p.W + 7) >> 3, tiles_y = (p.local_rows + 7) >> 3;
     const int total_slots = p.total_slots;
@@ -706,13 +723,13 @@ render_persistent_kernel(const RenderParams<T> p) {
             }
             if (alive) {
                 if (need_hit) { ++cost; if (COUNT) ++nseg; }
-                terminated = need_hit ? shade_step<T>(p, st, closest, hit, col) : true;   // camera.h:127 at the depth limit
+                terminated = need_hit ? shade_step<T>(p, lds_shade, st, closest, hit, col) : true;   // camera.h:127 at the depth limit
             }
         } else {
             if (COUNT) ++it_normal;
             if (alive) {
                 if (st.depth < p.B) { ++cost; if (COUNT) ++nseg; }
-                terminated = segment_step<T, SRC>(p, lds_geom, st, col);
+                terminated = segment_step<T, SRC>(p, lds_geom, lds_shade, st, col);
             }
         }
         if (alive && terminated) {
@@ -875,8 +892,7 @@ struct rtiow_handle_s {
 
     // scene
     int n = 0, n_padded = 0;
-    void *geom_a = nullptr, *geom_b = nullptr, *mat_a = nullptr, *mat_b = nullptr;
-    int* mat_type = nullptr;
+    void *geom_a = nullptr, *shade_tbl = nullptr;
     // camera
     bool have_camera = false;
     rtiow_camera_f32 cam32{};
@@ -964,8 +980,7 @@ RenderParams<T> make_params(const rtiow_handle_s* h, const CAM& c) {
     p.ddu = {c.defocus_disk_u[0], c.defocus_disk_u[1], c.defocus_disk_u[2]};
     p.ddv = {c.defocus_disk_v[0], c.defocus_disk_v[1], c.defocus_disk_v[2]};
     p.n = h->n; p.n_padded = h->n_padded;
-    p.geom_a = (const T*)h->geom_a; p.geom_b = (const T*)h->geom_b;
-    p.mat_a = (const T*)h->mat_a; p.mat_b = (const T*)h->mat_b; p.mat_type = h->mat_type;
+    p.geom_a = (const T*)h->geom_a; p.shade_tbl = (const T*)h->shade_tbl;
     p.rng = h->rng; p.fb = (T*)h->fb;
     p.local_rows = h->local_rows; p.rank = h->rank; p.nranks = h->nranks; p.strip_rows = h->strip_rows;
     return p;
@@ -973,18 +988,19 @@ RenderParams<T> make_params(const rtiow_handle_s* h, const CAM& c) {
 
 template <class T>
 int upload_scene(rtiow_handle_s* h, int n, const T* cr, const T* af, const T* ri, const int32_t* type, const int32_t* valid) {
-    std::vector<T> ga, gb, ma, mb; std::vector<int> mt;
+    std::vector<T> ga, st;
+    int m = 0;
     for (int i = 0; i < n; ++i) {
         if (valid && !valid[i]) continue;
         const T cx = cr[4 * i], cy = cr[4 * i + 1], cz = cr[4 * i + 2], r = cr[4 * i + 3];
         if (type[i] < 0 || type[i] > 2) return fail_arg(h, RTIOW_E_BADARG, "material type out of range");
         ga.insert(ga.end(), {cx, cy, cz, (T)(r * r)});          // hittable.h:45 radius*radius
-        gb.insert(gb.end(), {cx, cy, cz, (T)((T)1 / r)});       // vec3.h:89-91 (1/t)*v
-        ma.insert(ma.end(), {af[4 * i], af[4 * i + 1], af[4 * i + 2], af[4 * i + 3]});
-        mb.insert(mb.end(), {ri[i], (T)((T)1 / ri[i])});        // material.h:73 1.0f/refraction_index
-        mt.push_back(type[i]);
+        st.insert(st.end(), {cx, cy, cz, (T)((T)1 / r),         // vec3.h:89-91 (1/t)*v
+                             af[4 * i], af[4 * i + 1], af[4 * i + 2], af[4 * i + 3],
+                             ri[i], (T)((T)1 / ri[i]),          // material.h:73 1.0f/refraction_index
+                             (T)type[i], (T)0});
+        ++m;
     }
-    const int m = (int)mt.size();
     if (m == 0) return fail_arg(h, RTIOW_E_BADARG, "scene has no valid spheres");
     const int mp = (m + 3) / 4 * 4;
     for (int i = m; i < mp; ++i) ga.insert(ga.end(), {(T)0, (T)0, (T)0, (T)-1e12});   // c = |oc|^2 + 1e12 => disc < 0: never hit
@@ -994,18 +1010,12 @@ int upload_scene(rtiow_handle_s* h, int n, const T* cr, const T* af, const T* ri
             for (int k = 0; k < 4; ++k) { pi[8 * q + 2 * k] = ga[8 * q + k]; pi[8 * q + 2 * k + 1] = ga[8 * q + 4 + k]; }
         ga.swap(pi);
     }
-    void** bufs[] = {&h->geom_a, &h->geom_b, &h->mat_a, &h->mat_b, (void**)&h->mat_type};
+    void** bufs[] = {&h->geom_a, &h->shade_tbl};
     for (void** b : bufs) if (*b) { HIP_TRY(h, hipFree(*b)); *b = nullptr; }
     HIP_TRY(h, hipMalloc(&h->geom_a, sizeof(T) * 4 * mp));
-    HIP_TRY(h, hipMalloc(&h->geom_b, sizeof(T) * 4 * m));
-    HIP_TRY(h, hipMalloc(&h->mat_a, sizeof(T) * 4 * m));
-    HIP_TRY(h, hipMalloc(&h->mat_b, sizeof(T) * 2 * m));
-    HIP_TRY(h, hipMalloc((void**)&h->mat_type, sizeof(int) * m));
+    HIP_TRY(h, hipMalloc(&h->shade_tbl, sizeof(T) * 12 * m));
     HIP_TRY(h, hipMemcpy(h->geom_a, ga.data(), sizeof(T) * 4 * mp, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->geom_b, gb.data(), sizeof(T) * 4 * m, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->mat_a, ma.data(), sizeof(T) * 4 * m, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->mat_b, mb.data(), sizeof(T) * 2 * m, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->mat_type, mt.data(), sizeof(int) * m, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->shade_tbl, st.data(), sizeof(T) * 12 * m, hipMemcpyHostToDevice));
     h->n = m; h->n_padded = mp;
     h->stats.num_spheres = m;
     return 0;
@@ -1041,8 +1051,14 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     const int threads = bx * by;
     size_t lds = h->scene_source == RTIOW_SCENE_LDS ? sizeof(T) * 4 * (size_t)h->n_padded : 0;
     p.timeline = seg_counter ? h->timeline : nullptr;
-    p.coop_offset = (int)lds;                                // a multiple of 16 (n_padded % 4 == 0)
-    if (persistent) lds += (size_t)((threads + 63) / 64) * 64 * sizeof(CoopSlot<T>);
+    // shade records ride along in LDS while a workgroup's share stays within 1/5 of the CU's LDS
+    const size_t coop_bytes = persistent ? (size_t)((threads + 63) / 64) * 64 * sizeof(CoopSlot<T>) : 0;
+    const size_t shade_bytes = (sizeof(T) * 12 * (size_t)h->n + 15) / 16 * 16;
+    p.shade_offset = (int)lds;
+    p.shade_in_lds = (lds + shade_bytes + coop_bytes <= 32 * 1024) ? 1 : 0;
+    if (p.shade_in_lds) lds += shade_bytes;
+    p.coop_offset = (int)lds;                                // a multiple of 16
+    lds += coop_bytes;
     if (lds > 160 * 1024) return fail_arg(h, RTIOW_E_BADARG, "scene too large for LDS staging; use RTIOW_SCENE_SCALAR");
     RenderFn<T> k = pick_kernel<T>(persistent, h->scene_source == RTIOW_SCENE_LDS, seg_counter != nullptr);
     if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1088,7 +1104,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             RenderParams<T> pa = p;
             pa.s_end = SA; pa.rng_out = h->rng_mid; pa.acc_out = (T*)h->acc_mid; pa.cost_out = h->cost;
             pa.bx = 16; pa.by = 16; pa.wave_tiles = 1;
-            const size_t lds_a = h->scene_source == RTIOW_SCENE_LDS ? sizeof(T) * 4 * (size_t)h->n_padded : 0;
+            const size_t lds_a = lds - coop_bytes;       // same table layout, no coop scratch
             RenderFn<T> ka = pick_kernel<T>(false, h->scene_source == RTIOW_SCENE_LDS, seg_counter != nullptr);
             if (lds_a > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
             hipLaunchKernelGGL(ka, dim3((p.W + 15) / 16, (h->local_rows + 15) / 16), dim3(256), lds_a, h->stream, pa);
@@ -1179,7 +1195,7 @@ int rtiow_destroy(rtiow_handle h) {
     if (!h) return RTIOW_E_BADARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->geom_a, h->geom_b, h->mat_a, h->mat_b, h->mat_type, h->rng, h->jump, h->work_counter, h->rng_mid, h->acc_mid,
+    void* bufs[] = {h->geom_a, h->shade_tbl, h->rng, h->jump, h->work_counter, h->rng_mid, h->acc_mid,
                     h->cost, h->order, h->sort_scratch, h->fb_external ? nullptr : h->fb};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
