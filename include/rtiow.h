@@ -38,8 +38,10 @@ extern "C" {
 
 /* Scene-table source selected for the sphere loop (the AMD analogue of the reference's
  * global / constant / texture variants, README.md:7-12). */
-#define RTIOW_SCENE_LDS    0    /* sphere list staged into LDS per workgroup (default) */
-#define RTIOW_SCENE_SCALAR 1    /* wave-uniform scalar loads through the scalar cache  */
+#define RTIOW_SCENE_LDS       0 /* sphere list staged into LDS per workgroup (default); fp32 adds the
+                                 * 9-operation conservative screen in front of the exact test   */
+#define RTIOW_SCENE_SCALAR    1 /* wave-uniform scalar loads through the scalar cache, exact loop */
+#define RTIOW_SCENE_LDS_EXACT 2 /* LDS, the reference's 12-operation test on every sphere        */
 
 /* Pixel scheduling (same image either way):
  * STATIC     = the reference's launch geometry: grid of T x T blocks, one lane per pixel

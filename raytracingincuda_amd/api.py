@@ -21,7 +21,7 @@ import os
 import numpy as np
 
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
-SCENE_LDS, SCENE_SCALAR = 0, 1
+SCENE_LDS, SCENE_SCALAR, SCENE_LDS_EXACT = 0, 1, 2
 SCHED_STATIC, SCHED_PERSISTENT, SCHED_SORTED = 0, 1, 2
 
 _PKG = os.path.dirname(os.path.abspath(__file__))

@@ -25,6 +25,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -146,6 +147,11 @@ template <class T> struct RenderParams {
     V3<T> ddu, ddv;
     int n, n_padded;                  // spheres, and the table length padded to a multiple of 4
     const T* __restrict__ geom_a;     // [n_padded][4] cx,cy,cz,r*r (sphere loop; padding never hits)
+    // fp32 screening table (hit_world_screened): recentred centres and q' = |C'|^2 - r^2 - margin,
+    // pair-interleaved like geom_a; staged in LDS behind geom_a (screen_offset bytes)
+    const T* __restrict__ geom_s;
+    int use_screen, screen_offset;
+    T ctr_x, ctr_y, ctr_z, omax2;     // recentring point; omax2 = 2 Cmax of the per-ray margin term
     // everything the shade step needs about the sphere that was hit, 12 T per sphere:
     // {cx,cy,cz,1/r | albedo r,g,b,fuzz | eta, 1/eta, material type, 0}
     const T* __restrict__ shade_tbl;
@@ -358,6 +364,84 @@ __device__ __forceinline__ void hit_world_direct(const RenderParams<T>& p, const
     for (int s = 0; s < p.n_padded; s += 4) sphere_trip<T>(g, s, r, closest, hit);
 }
 
+// hit_sphere for ONE sphere, scalar, exactly the reference's arithmetic (used by the screened
+// loop for its rare candidates; the table is the pair-interleaved fp32 one).
+__device__ __forceinline__ void exact_sphere_test_f32(const float* g, int s, V3<float> O, V3<float> D, float a, float& closest, int& hit) {
+    const int base = (s >> 1) * 8 + (s & 1);
+    const float cx = g[base], cy = g[base + 2], cz = g[base + 4], r2 = g[base + 6];
+    const float ocx = cx - O.x, ocy = cy - O.y, ocz = cz - O.z;                                   // :42
+    const float h = __builtin_fmaf(D.z, ocz, __builtin_fmaf(D.y, ocy, D.x * ocx));                 // :44
+    const float c = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx)) - r2;            // :45
+    const float disc = __builtin_fmaf(h, h, -(a * c));                                            // :47
+    if (disc >= 0.0f) finish_sphere_test<float>(s, h, disc, a, closest, hit);                      // :48-57
+}
+
+// hit_world with a 9-operation SCREEN in front of the reference's 12-operation test (fp32).
+//
+// In exact arithmetic h = d.(C-O) = d.C - d.O and c = |C-O|^2 - r^2 = (|C|^2 - r^2) + |O|^2 - 2 O.C,
+// so with the per-ray constants k1 = d.O', k2 = |O'|^2, m = -2 O' (O' = O - centre) and the
+// per-sphere constant q = |C'|^2 - r^2 (C' = C - centre, precomputed) a sphere costs
+//     h~ = fma(dz,Cz', fma(dy,Cy', fma(dx,Cx', -k1)))      3
+//     c~ = fma(mz,Cz', fma(my,Cy', fma(mx,Cx', q + k2)))   4
+//     disc~ = fma(h~,h~, -(a*c~))                          2      = 9 instead of 12 (as 9 v_pk per PAIR).
+// disc~ is NOT the reference's discriminant (different roundings, cancellation), so it only
+// SCREENS: with E = 2^-18 a ((|C'|+|O'|)^2 + r^2) bounding |disc~ - Disc| + |disc_ref - Disc|
+// (derivation in DESIGN.md, constant 45u of slack-free bound vs 64u used), twice that margin is
+// subtracted from c~: the sphere's share 2^-17(|C'|^2 + r^2) is baked into q' by the host, the
+// ray's share 2^-17(2 Cmax |O'| + |O'|^2) (Cmax = max |C'| over the screened spheres) is folded
+// into k2, so that        disc_ref >= 0   =>   disc~' >= 0        for every ray and sphere.
+// A sphere with disc~' < 0 therefore fails the reference's `discriminant < 0` test (hittable.h:48)
+// and is skipped like there; every other sphere is re-tested with the reference's exact
+// arithmetic (exact_sphere_test_f32), in index order.  Spheres the bound would make useless
+// (|C'| > 64: the ground) get q' = -1e30 and are always re-tested.  Result: bit-identical.
+__device__ __forceinline__ void hit_world_screened(const RenderParams<float>& p, const float* lds_exact, const float* lds_screen,
+                                                   V3<float> O, V3<float> D, float a, float& closest, int& hit) {
+    float ox = O.x - p.ctr_x, oy = O.y - p.ctr_y, oz = O.z - p.ctr_z;
+    float nk1 = -__builtin_fmaf(D.z, oz, __builtin_fmaf(D.y, oy, D.x * ox));
+    float k2 = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+    k2 = k2 - 7.62939453125e-06f * __builtin_fmaf(p.omax2, __builtin_sqrtf(k2), k2);   // - 2^-17 (2 Cmax |O'| + |O'|^2); p.omax2 holds 2 Cmax
+    float mx = -2.0f * ox, my = -2.0f * oy, mz = -2.0f * oz;
+    float dx = D.x, dy = D.y, dz = D.z, aa = a;
+    asm volatile("" : "+v"(nk1), "+v"(k2), "+v"(mx), "+v"(my), "+v"(mz), "+v"(dx), "+v"(dy), "+v"(dz), "+v"(aa));
+    const v2f vnk1 = {nk1, nk1}, vk2 = {k2, k2}, vmx = {mx, mx}, vmy = {my, my}, vmz = {mz, mz};
+    const v2f vdx = {dx, dx}, vdy = {dy, dy}, vdz = {dz, dz}, vaa = {aa, aa};
+    for (int s = 0; s < p.n_padded; s += 4) {
+        const v4f* g4 = reinterpret_cast<const v4f*>(lds_screen + 4 * s);
+        const v4f p0 = g4[0], p1 = g4[1], p2 = g4[2], p3 = g4[3];
+        v2f dsc[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const v4f lo = q ? p2 : p0, hi = q ? p3 : p1;
+            const v2f cx = {lo.x, lo.y}, cy = {lo.z, lo.w}, cz = {hi.x, hi.y}, qq = {hi.z, hi.w};
+            const v2f hh = __builtin_elementwise_fma(vdz, cz, __builtin_elementwise_fma(vdy, cy, __builtin_elementwise_fma(vdx, cx, vnk1)));
+            const v2f cc = __builtin_elementwise_fma(vmz, cz, __builtin_elementwise_fma(vmy, cy, __builtin_elementwise_fma(vmx, cx, qq + vk2)));
+            dsc[q] = __builtin_elementwise_fma(hh, hh, -(vaa * cc));
+        }
+        const float m = __builtin_fmaxf(__builtin_fmaxf(dsc[0].x, dsc[0].y), __builtin_fmaxf(dsc[1].x, dsc[1].y));
+        if (!(m < 0.0f)) {                        // some sphere of the trip may pass hittable.h:48 (NaNs are kept)
+            if (!(dsc[0].x < 0.0f)) exact_sphere_test_f32(lds_exact, s + 0, O, D, a, closest, hit);
+            if (!(dsc[0].y < 0.0f)) exact_sphere_test_f32(lds_exact, s + 1, O, D, a, closest, hit);
+            if (!(dsc[1].x < 0.0f)) exact_sphere_test_f32(lds_exact, s + 2, O, D, a, closest, hit);
+            if (!(dsc[1].y < 0.0f)) exact_sphere_test_f32(lds_exact, s + 3, O, D, a, closest, hit);
+        }
+    }
+}
+
+template <class T, int SRC>
+__device__ __forceinline__ void hit_world(const RenderParams<T>& p, const T* lds_geom, V3<T> O, V3<T> D, T a, T& closest, int& hit) {
+    hit_world_direct<T, SRC>(p, lds_geom, O, D, a, closest, hit);
+}
+template <>
+__device__ __forceinline__ void hit_world<float, RTIOW_SCENE_LDS>(const RenderParams<float>& p, const float* lds_geom, V3<float> O, V3<float> D,
+                                                                  float a, float& closest, int& hit) {
+    if (p.use_screen) {
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+        hit_world_screened(p, lds_geom, reinterpret_cast<const float*>(smem_raw + p.screen_offset), O, D, a, closest, hit);
+    } else {
+        hit_world_direct<float, RTIOW_SCENE_LDS>(p, lds_geom, O, D, a, closest, hit);
+    }
+}
+
 // Per-lane path state of the flattened samples x bounces loop.
 template <class T> struct PathState {
     V3<T> O, D, atten, acc;
@@ -452,7 +536,7 @@ __device__ __forceinline__ bool segment_step(const RenderParams<T>& p, const T* 
     T closest = __builtin_huge_val();
     int hit = -1;
     const T a = dot3(st.D, st.D);                 // hittable.h:43, ray-invariant
-    hit_world_direct<T, SRC>(p, lds_geom, st.O, st.D, a, closest, hit);
+    hit_world<T, SRC>(p, lds_geom, st.O, st.D, a, closest, hit);
     return shade_step<T>(p, lds_shade, st, closest, hit, col);
 }
 
@@ -528,8 +612,13 @@ __device__ __forceinline__ T* stage_scene(const RenderParams<T>& p) {
     if (SRC == RTIOW_SCENE_LDS || p.shade_in_lds) {
         // Stage the loop table {cx,cy,cz,r^2} (and the shade records when they fit): coalesced
         // global reads, one pass.
-        if (SRC == RTIOW_SCENE_LDS)
+        if (SRC == RTIOW_SCENE_LDS) {
             for (int k = threadIdx.x; k < p.n_padded * 4; k += blockDim.x) lds_geom[k] = p.geom_a[k];
+            if (p.use_screen) {
+                T* lds_screen = reinterpret_cast<T*>(smem_raw + p.screen_offset);
+                for (int k = threadIdx.x; k < p.n_padded * 4; k += blockDim.x) lds_screen[k] = p.geom_s[k];
+            }
+        }
         if (p.shade_in_lds) {
             T* lds_shade = reinterpret_cast<T*>(smem_raw + p.shade_offset);
             for (int k = threadIdx.x; k < p.n * 12; k += blockDim.x) lds_shade[k] = p.shade_tbl[k];
@@ -893,6 +982,10 @@ struct rtiow_handle_s {
     // scene
     int n = 0, n_padded = 0;
     void *geom_a = nullptr, *shade_tbl = nullptr;
+    float* geom_s = nullptr;                      // fp32 screening table (built lazily: depends on the camera too)
+    std::vector<float> host_cr;                   // compact {cx,cy,cz,r} kept for building it
+    bool screen_dirty = true;
+    float ctr[3] = {0, 0, 0}, omax2 = 0;
     // camera
     bool have_camera = false;
     rtiow_camera_f32 cam32{};
@@ -1010,6 +1103,11 @@ int upload_scene(rtiow_handle_s* h, int n, const T* cr, const T* af, const T* ri
             for (int k = 0; k < 4; ++k) { pi[8 * q + 2 * k] = ga[8 * q + k]; pi[8 * q + 2 * k + 1] = ga[8 * q + 4 + k]; }
         ga.swap(pi);
     }
+    h->host_cr.clear();
+    if (sizeof(T) == 4)
+        for (int i = 0; i < n; ++i)
+            if (!valid || valid[i]) for (int k = 0; k < 4; ++k) h->host_cr.push_back((float)cr[4 * i + k]);
+    h->screen_dirty = true;
     void** bufs[] = {&h->geom_a, &h->shade_tbl};
     for (void** b : bufs) if (*b) { HIP_TRY(h, hipFree(*b)); *b = nullptr; }
     HIP_TRY(h, hipMalloc(&h->geom_a, sizeof(T) * 4 * mp));
@@ -1020,6 +1118,57 @@ int upload_scene(rtiow_handle_s* h, int n, const T* cr, const T* af, const T* ri
     h->stats.num_spheres = m;
     return 0;
 }
+
+// Builds the fp32 screening table of hit_world_screened for the current scene + camera:
+// centres recentred on the scene's centroid (ground-like spheres excluded), and
+// q' = |C'|^2 - r^2 - 2^-17 ((|C'| + Omax)^2 + r^2), rounded DOWN, pair-interleaved.
+int build_screen_table(rtiow_handle_s* h) {
+    const int m = h->n, mp = h->n_padded;
+    const std::vector<float>& cr = h->host_cr;
+    double ctr[3] = {0, 0, 0};
+    int cnt = 0;
+    for (int i = 0; i < m; ++i)
+        if (cr[4 * i + 3] < 100.0f) { for (int k = 0; k < 3; ++k) ctr[k] += cr[4 * i + k]; ++cnt; }
+    if (cnt) for (int k = 0; k < 3; ++k) ctr[k] /= cnt;
+    for (int k = 0; k < 3; ++k) h->ctr[k] = (float)ctr[k];
+    std::vector<float> lin((size_t)mp * 4);
+    double cmax = 0;                                        // max |C'| over the spheres that are screened
+    for (int i = 0; i < mp; ++i) {
+        if (i >= m) { lin[4 * i] = lin[4 * i + 1] = lin[4 * i + 2] = 0; lin[4 * i + 3] = 1e12f; continue; }   // padding: c~ huge => never a candidate
+        double c2 = 0;
+        for (int k = 0; k < 3; ++k) {
+            const float cp = (float)((double)cr[4 * i + k] - (double)h->ctr[k]);   // what the kernel will use as C'
+            lin[4 * i + k] = cp;
+            c2 += (double)cp * (double)cp;
+        }
+        if (std::sqrt(c2) > 64.0) { lin[4 * i + 3] = -1e30f; continue; }           // e.g. the ground: always re-tested exactly
+        cmax = std::max(cmax, std::sqrt(c2));
+        const double r = cr[4 * i + 3], r2 = r * r;
+        const double kappa = std::ldexp(1.0, -17) * (c2 + r2);                     // the sphere's share of the margin
+        float q = (float)(c2 - r2 - kappa);
+        if ((double)q > c2 - r2 - kappa) q = std::nextafterf(q, -INFINITY);
+        lin[4 * i + 3] = q;
+    }
+    h->omax2 = (float)(2.0 * cmax * 1.0000001);            // per-ray share uses 2 Cmax |O'| + |O'|^2
+    std::vector<float> pi(lin.size());
+    for (int q = 0; q < mp / 2; ++q)
+        for (int k = 0; k < 4; ++k) { pi[8 * q + 2 * k] = lin[8 * q + k]; pi[8 * q + 2 * k + 1] = lin[8 * q + 4 + k]; }
+    if (h->geom_s) { HIP_TRY(h, hipFree(h->geom_s)); h->geom_s = nullptr; }
+    HIP_TRY(h, hipMalloc((void**)&h->geom_s, pi.size() * sizeof(float)));
+    HIP_TRY(h, hipMemcpy(h->geom_s, pi.data(), pi.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->screen_dirty = false;
+    return 0;
+}
+
+template <class T> struct ScreenParams {
+    static void fill(RenderParams<T>& p, const rtiow_handle_s*) { p.geom_s = nullptr; p.use_screen = 0; p.ctr_x = p.ctr_y = p.ctr_z = 0; p.omax2 = 0; }
+};
+template <> struct ScreenParams<float> {
+    static void fill(RenderParams<float>& p, const rtiow_handle_s* h) {
+        p.geom_s = h->geom_s; p.use_screen = (h->scene_source == RTIOW_SCENE_LDS && h->geom_s) ? 1 : 0;
+        p.ctr_x = h->ctr[0]; p.ctr_y = h->ctr[1]; p.ctr_z = h->ctr[2]; p.omax2 = h->omax2;
+    }
+};
 
 template <class T> using RenderFn = void (*)(const RenderParams<T>);
 
@@ -1049,18 +1198,25 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     p.bx = bx; p.by = by; p.wave_tiles = wave_tiles; p.seg_counter = seg_counter;
     const bool persistent = h->schedule != RTIOW_SCHED_STATIC;
     const int threads = bx * by;
-    size_t lds = h->scene_source == RTIOW_SCENE_LDS ? sizeof(T) * 4 * (size_t)h->n_padded : 0;
+    const bool lds_source = h->scene_source != RTIOW_SCENE_SCALAR;
+    if (sizeof(T) == 4 && h->scene_source == RTIOW_SCENE_LDS && h->screen_dirty) { int rc = build_screen_table(h); if (rc) return rc; }
+    ScreenParams<T>::fill(p, h);
+    size_t lds = lds_source ? sizeof(T) * 4 * (size_t)h->n_padded : 0;
+    p.screen_offset = (int)lds;
+    if (p.use_screen) lds += sizeof(T) * 4 * (size_t)h->n_padded;
     p.timeline = seg_counter ? h->timeline : nullptr;
     // shade records ride along in LDS while a workgroup's share stays within 1/5 of the CU's LDS
     const size_t coop_bytes = persistent ? (size_t)((threads + 63) / 64) * 64 * sizeof(CoopSlot<T>) : 0;
     const size_t shade_bytes = (sizeof(T) * 12 * (size_t)h->n + 15) / 16 * 16;
     p.shade_offset = (int)lds;
-    p.shade_in_lds = (lds + shade_bytes + coop_bytes <= 32 * 1024) ? 1 : 0;
+    // ... and a wave's share stays under ~6.5 KB, so that LDS never caps occupancy below 6 waves/SIMD
+    const size_t waves_in_block = (size_t)((threads + 63) / 64);
+    p.shade_in_lds = (lds + shade_bytes + coop_bytes <= 32 * 1024 && (lds + shade_bytes + coop_bytes) / waves_in_block <= 6656) ? 1 : 0;
     if (p.shade_in_lds) lds += shade_bytes;
     p.coop_offset = (int)lds;                                // a multiple of 16
     lds += coop_bytes;
     if (lds > 160 * 1024) return fail_arg(h, RTIOW_E_BADARG, "scene too large for LDS staging; use RTIOW_SCENE_SCALAR");
-    RenderFn<T> k = pick_kernel<T>(persistent, h->scene_source == RTIOW_SCENE_LDS, seg_counter != nullptr);
+    RenderFn<T> k = pick_kernel<T>(persistent, lds_source, seg_counter != nullptr);
     if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipFuncAttributes fa{};
     HIP_TRY(h, hipFuncGetAttributes(&fa, (const void*)k));
@@ -1105,7 +1261,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             pa.s_end = SA; pa.rng_out = h->rng_mid; pa.acc_out = (T*)h->acc_mid; pa.cost_out = h->cost;
             pa.bx = 16; pa.by = 16; pa.wave_tiles = 1;
             const size_t lds_a = lds - coop_bytes;       // same table layout, no coop scratch
-            RenderFn<T> ka = pick_kernel<T>(false, h->scene_source == RTIOW_SCENE_LDS, seg_counter != nullptr);
+            RenderFn<T> ka = pick_kernel<T>(false, lds_source, seg_counter != nullptr);
             if (lds_a > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
             hipLaunchKernelGGL(ka, dim3((p.W + 15) / 16, (h->local_rows + 15) / 16), dim3(256), lds_a, h->stream, pa);
             HIP_TRY(h, hipGetLastError());
@@ -1195,7 +1351,7 @@ int rtiow_destroy(rtiow_handle h) {
     if (!h) return RTIOW_E_BADARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->geom_a, h->shade_tbl, h->rng, h->jump, h->work_counter, h->rng_mid, h->acc_mid,
+    void* bufs[] = {h->geom_a, h->shade_tbl, h->geom_s, h->rng, h->jump, h->work_counter, h->rng_mid, h->acc_mid,
                     h->cost, h->order, h->sort_scratch, h->fb_external ? nullptr : h->fb};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1232,6 +1388,7 @@ int rtiow_set_camera(rtiow_handle h, const void* camera) {
     else { h->cam64 = *(const rtiow_camera_f64*)camera; W = h->cam64.img_width; H = h->cam64.img_height; S = h->cam64.samples_per_pixel; }
     if (W <= 0 || H <= 0 || S < 0 || (int64_t)W * H > 0x7fffffffLL) { h->have_camera = false; return fail_arg(h, RTIOW_E_BADARG, "rtiow_set_camera: bad image size"); }
     h->have_camera = true;
+    h->screen_dirty = true;
     h->local_rows = compute_local_rows(H, h->rank, h->nranks, h->strip_rows);
     h->stats.local_rows = h->local_rows;
     h->rng_ready = false;
@@ -1388,7 +1545,7 @@ int rtiow_read_framebuffer(rtiow_handle h, void* host_rgb, size_t bytes) {
 
 int rtiow_set_scene_source(rtiow_handle h, int scene_source) {
     if (!h) return RTIOW_E_BADARG;
-    if (scene_source != RTIOW_SCENE_LDS && scene_source != RTIOW_SCENE_SCALAR) return fail_arg(h, RTIOW_E_BADARG, "unknown scene source");
+    if (scene_source != RTIOW_SCENE_LDS && scene_source != RTIOW_SCENE_SCALAR && scene_source != RTIOW_SCENE_LDS_EXACT) return fail_arg(h, RTIOW_E_BADARG, "unknown scene source");
     h->scene_source = scene_source;
     return 0;
 }

@@ -10,7 +10,7 @@ def main(scene_id=3, W=1920, H=1080, S=100, B=50, prec=32, rounds=5, shard=None,
     if shard: r.set_shard(*shard)
     r.init_rng(1227)
     # (source, threads, sched, waves_per_simd)
-    variants = variants or [(0, 0, 0, 0), (0, 0, 1, 0), (0, 0, 2, 0), (0, 8, 2, 0), (0, 0, 2, 4), (0, 0, 2, 3)]
+    variants = variants or [(2, 0, 2, 0), (0, 0, 2, 0), (0, 8, 2, 0), (0, 16, 2, 0), (0, 32, 2, 0), (0, 8, 1, 0), (0, 8, 0, 0)]
     times = {v: [] for v in variants}
     ref = None
     for rd in range(rounds):
@@ -31,7 +31,7 @@ def main(scene_id=3, W=1920, H=1080, S=100, B=50, prec=32, rounds=5, shard=None,
 
 if __name__ == "__main__":
     main(3)
-    main(3, shard=(3, 8, 8), variants=[(0, 0, 0, 0), (0, 0, 1, 0), (0, 0, 2, 0), (0, 0, 2, 3)])
-    main(3, shard=(1, 2, 8), variants=[(0, 0, 1, 0), (0, 0, 2, 0)])
-    main(1, rounds=3, variants=[(0, 0, 0, 0), (0, 0, 1, 0), (0, 0, 2, 0)])
-    main(3, prec=64, rounds=3, variants=[(0, 0, 0, 0), (0, 0, 1, 0), (0, 0, 2, 0), (1, 0, 2, 0)])
+    main(3, shard=(3, 8, 8), variants=[(2, 0, 2, 0), (0, 0, 2, 0)])
+    main(3, shard=(1, 2, 8), variants=[(2, 0, 2, 0), (0, 0, 2, 0)])
+    main(1, rounds=3, variants=[(2, 0, 1, 0), (0, 0, 1, 0), (2, 0, 2, 0), (0, 0, 2, 0)])
+    main(3, prec=64, rounds=3, variants=[(0, 0, 1, 0), (0, 0, 2, 0)])

@@ -141,7 +141,7 @@ def test_render_bit_exact_vs_oracle(rt, oracle, prec, scene_id, W, H, S, B):
 def test_block_shapes_and_scene_sources_give_the_same_image(rt, oracle):
     want, _ = _oracle(oracle, rt, 32, 3, 100, 60, 3, 12)
     for threads in (0, 1, 4, 8, 16, 32):
-        for source in (rt.SCENE_LDS, rt.SCENE_SCALAR):
+        for source in (rt.SCENE_LDS, rt.SCENE_SCALAR, rt.SCENE_LDS_EXACT):
             for sched, wps in ((rt.SCHED_SORTED, 0), (rt.SCHED_PERSISTENT, 0), (rt.SCHED_PERSISTENT, 1), (rt.SCHED_STATIC, 0)):
                 got = _render(rt, 32, 3, 100, 60, 3, 12, threads, source, sched=sched, wps=wps)
                 assert _same_bits(got, want), (threads, source, sched, wps)
@@ -250,6 +250,13 @@ def test_benchmark_harness_csv_round_trip(rt, tmp_path):
     assert len(open(avg).read().splitlines()) == 1 + 4
 
 
+def test_screen_equals_exact_on_the_488_sphere_scene(rt):
+    """Scene 1 at 1280x720x20: the screened loop (default) vs the exact loop, bit for bit."""
+    a = _render(rt, 32, 1, 1280, 720, 20, 50, threads=0)
+    b = _render(rt, 32, 1, 1280, 720, 20, 50, threads=0, source=rt.SCENE_LDS_EXACT)
+    assert _same_bits(a, b)
+
+
 def test_full_size_properties(rt, oracle):
     """BASELINE headline config (scene 3, 1920x1080, 100 spp, 50 bounces): too big for the
     oracle in full, so: (1) run-to-run determinism, (2) 8-way sharded == whole image,
@@ -264,6 +271,9 @@ def test_full_size_properties(rt, oracle):
         b = r.read_framebuffer()
         segs = r.count_segments(0)
     assert _same_bits(a, b)
+    # the fp32 screen in front of the exact sphere test (default) vs the exact test on every
+    # sphere: 6e10 sphere tests must not differ in a single bit
+    assert _same_bits(a, _render(rt, 32, 3, W, H, S, B, threads=0, source=rt.SCENE_LDS_EXACT, sched=rt.SCHED_STATIC))
     assert np.isfinite(a).all() and a.min() >= 0 and a.max() <= 1.0 + 1e-6
     assert 2.0 < segs / (W * H * S) < 2.6          # 2.24 segments per primary ray
     full = np.zeros_like(a)
