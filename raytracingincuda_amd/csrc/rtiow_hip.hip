@@ -1242,7 +1242,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         const int npix = p.W * h->local_rows;
         const int S = p.S;
         // phase A length: enough samples to rank the pixels, a small share of the frame
-        const int SA = S >= 64 ? 4 : (S >= 24 ? 2 : 0);
+        const int SA = S >= 64 ? 4 : (S >= 24 ? 2 : 0);   // 2..6 measured equal on the headline config
         p.work_counter = h->work_counter;
         p.s_begin = 0; p.s_end = S; p.rng_in = h->rng; p.rng_out = nullptr; p.acc_in = nullptr; p.acc_out = nullptr;
         p.cost_out = nullptr; p.order = nullptr; p.total_slots = (int)tile_slots; p.first_pools = 0;
@@ -1277,7 +1277,6 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             const int age_classes = (int)((blocks + h->num_cus - 1) / h->num_cus);
             int pools_per_block = (resident_waves + age_classes - 1) / age_classes;
             if (pools_per_block > total_pools) pools_per_block = total_pools;
-            if (const char* e = std::getenv("RTIOW_DEBUG_POOLS_PER_BLOCK")) { const int v = std::atoi(e); if (v >= 1) pools_per_block = v < total_pools ? v : total_pools; }
             const int scatter_blocks = (npix + 1024 * SCATTER_PER_THREAD - 1) / (1024 * SCATTER_PER_THREAD);
             hipLaunchKernelGGL(cost_scatter_kernel, dim3(scatter_blocks), dim3(1024), 0, h->stream, h->cost, npix, start, fill, h->order,
                                pools_per_block, total_pools);
@@ -1285,10 +1284,9 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             // ---- phase B: samples [SA, S) in that order
             p.s_begin = SA; p.rng_in = h->rng_mid; p.acc_in = (const T*)h->acc_mid; p.order = h->order;
             p.total_slots = total_pools * POOL;
-            if (std::getenv("RTIOW_DEBUG_NO_SORT")) { p.order = nullptr; p.total_slots = (int)tile_slots; }
             p.work_counter = h->work_counter + 1;
-            p.first_pools = std::getenv("RTIOW_DEBUG_NO_FIRST") ? 0 : 1;
-            const unsigned counter_start = p.first_pools ? (unsigned)resident_waves * POOL : 0u;
+            p.first_pools = 1;
+            const unsigned counter_start = (unsigned)resident_waves * POOL;
             HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)(h->work_counter + 1), (int)counter_start, 1, h->stream));
         }
     } else {

@@ -6,12 +6,14 @@ bound).  Usage: collect_traffic.py <fetch_dir> <write_dir> <key> [out.json]"""
 import csv, glob, json, os, sys
 
 def mean_counter(d, name):
-    vals = []
+    """Bytes of ONE render = sum over its kernels (phase A, sort, phase B) of the mean per dispatch."""
+    per_kernel = {}
     for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "render" in r["Kernel_Name"] and r["Counter_Name"] == name:
-                vals.append(float(r["Counter_Value"]))
-    return sum(vals) / len(vals) if vals else None
+            k = r["Kernel_Name"]
+            if ("render" in k or "cost_" in k) and r["Counter_Name"] == name:
+                per_kernel.setdefault(k.split("(")[0], []).append(float(r["Counter_Value"]))
+    return sum(sum(v) / len(v) for v in per_kernel.values()) if per_kernel else None
 
 fetch_dir, write_dir, key = sys.argv[1:4]
 out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
