@@ -383,7 +383,9 @@ __device__ __forceinline__ void exact_sphere_test_f32(const float* g, int s, V3<
 // per-sphere constant q = |C'|^2 - r^2 (C' = C - centre, precomputed) a sphere costs
 //     h~ = fma(dz,Cz', fma(dy,Cy', fma(dx,Cx', -k1)))      3
 //     c~ = fma(mz,Cz', fma(my,Cy', fma(mx,Cx', q + k2)))   4
-//     disc~ = fma(h~,h~, -(a*c~))                          2      = 9 instead of 12 (as 9 v_pk per PAIR).
+//     disc~ = fma(h~,h~, -c~)        (d pre-scaled to unit length, so a = 1)   1      = 8 instead of 12
+// (8 v_pk per PAIR of spheres).  The unit direction uses the raw v_rsq (2^-22): only the sign of
+// disc~ matters and disc/a has the same sign as disc, the rsq error is covered by the margin.
 // disc~ is NOT the reference's discriminant (different roundings, cancellation), so it only
 // SCREENS: with E = 2^-18 a ((|C'|+|O'|)^2 + r^2) bounding |disc~ - Disc| + |disc_ref - Disc|
 // (derivation in DESIGN.md, constant 45u of slack-free bound vs 64u used), twice that margin is
@@ -397,14 +399,15 @@ __device__ __forceinline__ void exact_sphere_test_f32(const float* g, int s, V3<
 __device__ __forceinline__ void hit_world_screened(const RenderParams<float>& p, const float* lds_exact, const float* lds_screen,
                                                    V3<float> O, V3<float> D, float a, float& closest, int& hit) {
     float ox = O.x - p.ctr_x, oy = O.y - p.ctr_y, oz = O.z - p.ctr_z;
-    float nk1 = -__builtin_fmaf(D.z, oz, __builtin_fmaf(D.y, oy, D.x * ox));
+    const float rs = __builtin_amdgcn_rsqf(a);    // screen only: |d^| = 1 +- 2^-22
+    float dx = D.x * rs, dy = D.y * rs, dz = D.z * rs;
+    float nk1 = -__builtin_fmaf(dz, oz, __builtin_fmaf(dy, oy, dx * ox));
     float k2 = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
     k2 = k2 - 7.62939453125e-06f * __builtin_fmaf(p.omax2, __builtin_sqrtf(k2), k2);   // - 2^-17 (2 Cmax |O'| + |O'|^2); p.omax2 holds 2 Cmax
     float mx = -2.0f * ox, my = -2.0f * oy, mz = -2.0f * oz;
-    float dx = D.x, dy = D.y, dz = D.z, aa = a;
-    asm volatile("" : "+v"(nk1), "+v"(k2), "+v"(mx), "+v"(my), "+v"(mz), "+v"(dx), "+v"(dy), "+v"(dz), "+v"(aa));
+    asm volatile("" : "+v"(nk1), "+v"(k2), "+v"(mx), "+v"(my), "+v"(mz), "+v"(dx), "+v"(dy), "+v"(dz));
     const v2f vnk1 = {nk1, nk1}, vk2 = {k2, k2}, vmx = {mx, mx}, vmy = {my, my}, vmz = {mz, mz};
-    const v2f vdx = {dx, dx}, vdy = {dy, dy}, vdz = {dz, dz}, vaa = {aa, aa};
+    const v2f vdx = {dx, dx}, vdy = {dy, dy}, vdz = {dz, dz};
     for (int s = 0; s < p.n_padded; s += 4) {
         const v4f* g4 = reinterpret_cast<const v4f*>(lds_screen + 4 * s);
         const v4f p0 = g4[0], p1 = g4[1], p2 = g4[2], p3 = g4[3];
@@ -415,7 +418,7 @@ __device__ __forceinline__ void hit_world_screened(const RenderParams<float>& p,
             const v2f cx = {lo.x, lo.y}, cy = {lo.z, lo.w}, cz = {hi.x, hi.y}, qq = {hi.z, hi.w};
             const v2f hh = __builtin_elementwise_fma(vdz, cz, __builtin_elementwise_fma(vdy, cy, __builtin_elementwise_fma(vdx, cx, vnk1)));
             const v2f cc = __builtin_elementwise_fma(vmz, cz, __builtin_elementwise_fma(vmy, cy, __builtin_elementwise_fma(vmx, cx, qq + vk2)));
-            dsc[q] = __builtin_elementwise_fma(hh, hh, -(vaa * cc));
+            dsc[q] = __builtin_elementwise_fma(hh, hh, -cc);
         }
         const float m = __builtin_fmaxf(__builtin_fmaxf(dsc[0].x, dsc[0].y), __builtin_fmaxf(dsc[1].x, dsc[1].y));
         if (!(m < 0.0f)) {                        // some sphere of the trip may pass hittable.h:48 (NaNs are kept)

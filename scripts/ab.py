@@ -10,7 +10,7 @@ def main(scene_id=3, W=1920, H=1080, S=100, B=50, prec=32, rounds=5, shard=None,
     if shard: r.set_shard(*shard)
     r.init_rng(1227)
     # (source, threads, sched, waves_per_simd)
-    variants = variants or [(2, 0, 2, 0), (0, 0, 2, 0), (0, 8, 2, 0), (0, 16, 2, 0), (0, 32, 2, 0), (0, 8, 1, 0), (0, 8, 0, 0)]
+    variants = variants or [(2, 0, 2, 0), (0, 0, 2, 0), (0, 8, 2, 0)]
     times = {v: [] for v in variants}
     ref = None
     for rd in range(rounds):
