@@ -430,9 +430,59 @@ __device__ __forceinline__ void hit_world_screened(const RenderParams<float>& p,
     }
 }
 
+// fp64 twin of the screen: scalar operations on the plain {cx',cy',cz',q'} table (8 instead of 12
+// per sphere).  It keeps the fp32 margins (2^-17): the raw v_rsq_f64 behind the unit direction is
+// only ~2^-26 accurate, which those margins cover a hundred times over, and the false-positive
+// rate (+3 % candidates) is what fp32 pays anyway.
+__device__ __forceinline__ void exact_sphere_test_f64(const double* g, int s, V3<double> O, V3<double> D, double a, double& closest, int& hit) {
+    const double cx = g[4 * s], cy = g[4 * s + 1], cz = g[4 * s + 2], r2 = g[4 * s + 3];
+    const double ocx = cx - O.x, ocy = cy - O.y, ocz = cz - O.z;                                   // :42
+    const double h = __builtin_fma(D.z, ocz, __builtin_fma(D.y, ocy, D.x * ocx));                  // :44
+    const double c = __builtin_fma(ocz, ocz, __builtin_fma(ocy, ocy, ocx * ocx)) - r2;             // :45
+    const double disc = __builtin_fma(h, h, -(a * c));                                             // :47
+    if (disc >= 0.0) finish_sphere_test<double>(s, h, disc, a, closest, hit);                      // :48-57
+}
+
+__device__ __forceinline__ void hit_world_screened(const RenderParams<double>& p, const double* lds_exact, const double* lds_screen,
+                                                   V3<double> O, V3<double> D, double a, double& closest, int& hit) {
+    const double ox = O.x - p.ctr_x, oy = O.y - p.ctr_y, oz = O.z - p.ctr_z;
+    const double rs = __builtin_amdgcn_rsq(a);
+    const double dx = D.x * rs, dy = D.y * rs, dz = D.z * rs;
+    const double nk1 = -__builtin_fma(dz, oz, __builtin_fma(dy, oy, dx * ox));
+    double k2 = __builtin_fma(oz, oz, __builtin_fma(oy, oy, ox * ox));
+    k2 = k2 - 7.62939453125e-06 * __builtin_fma(p.omax2, __builtin_sqrt(k2), k2);
+    const double mx = -2.0 * ox, my = -2.0 * oy, mz = -2.0 * oz;
+    for (int s = 0; s < p.n_padded; s += 4) {
+        double dsc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double cx = lds_screen[4 * (s + k)], cy = lds_screen[4 * (s + k) + 1], cz = lds_screen[4 * (s + k) + 2], qq = lds_screen[4 * (s + k) + 3];
+            const double hh = __builtin_fma(dz, cz, __builtin_fma(dy, cy, __builtin_fma(dx, cx, nk1)));
+            const double cc = __builtin_fma(mz, cz, __builtin_fma(my, cy, __builtin_fma(mx, cx, qq + k2)));
+            dsc[k] = __builtin_fma(hh, hh, -cc);
+        }
+        const double m = __builtin_fmax(__builtin_fmax(dsc[0], dsc[1]), __builtin_fmax(dsc[2], dsc[3]));
+        if (!(m < 0.0)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (!(dsc[k] < 0.0)) exact_sphere_test_f64(lds_exact, s + k, O, D, a, closest, hit);
+        }
+    }
+}
+
 template <class T, int SRC>
 __device__ __forceinline__ void hit_world(const RenderParams<T>& p, const T* lds_geom, V3<T> O, V3<T> D, T a, T& closest, int& hit) {
     hit_world_direct<T, SRC>(p, lds_geom, O, D, a, closest, hit);
+}
+template <>
+__device__ __forceinline__ void hit_world<double, RTIOW_SCENE_LDS>(const RenderParams<double>& p, const double* lds_geom, V3<double> O, V3<double> D,
+                                                                   double a, double& closest, int& hit) {
+    if (p.use_screen) {
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+        hit_world_screened(p, lds_geom, reinterpret_cast<const double*>(smem_raw + p.screen_offset), O, D, a, closest, hit);
+    } else {
+        hit_world_direct<double, RTIOW_SCENE_LDS>(p, lds_geom, O, D, a, closest, hit);
+    }
 }
 template <>
 __device__ __forceinline__ void hit_world<float, RTIOW_SCENE_LDS>(const RenderParams<float>& p, const float* lds_geom, V3<float> O, V3<float> D,
@@ -985,10 +1035,10 @@ struct rtiow_handle_s {
     // scene
     int n = 0, n_padded = 0;
     void *geom_a = nullptr, *shade_tbl = nullptr;
-    float* geom_s = nullptr;                      // fp32 screening table (built lazily: depends on the camera too)
-    std::vector<float> host_cr;                   // compact {cx,cy,cz,r} kept for building it
+    void* geom_s = nullptr;                       // screening table (built lazily at the first render of a scene)
+    std::vector<double> host_cr;                  // compact {cx,cy,cz,r} kept for building it
     bool screen_dirty = true;
-    float ctr[3] = {0, 0, 0}, omax2 = 0;
+    double ctr[3] = {0, 0, 0}, omax2 = 0;
     // camera
     bool have_camera = false;
     rtiow_camera_f32 cam32{};
@@ -1107,9 +1157,8 @@ int upload_scene(rtiow_handle_s* h, int n, const T* cr, const T* af, const T* ri
         ga.swap(pi);
     }
     h->host_cr.clear();
-    if (sizeof(T) == 4)
-        for (int i = 0; i < n; ++i)
-            if (!valid || valid[i]) for (int k = 0; k < 4; ++k) h->host_cr.push_back((float)cr[4 * i + k]);
+    for (int i = 0; i < n; ++i)
+        if (!valid || valid[i]) for (int k = 0; k < 4; ++k) h->host_cr.push_back((double)cr[4 * i + k]);
     h->screen_dirty = true;
     void** bufs[] = {&h->geom_a, &h->shade_tbl};
     for (void** b : bufs) if (*b) { HIP_TRY(h, hipFree(*b)); *b = nullptr; }
@@ -1122,56 +1171,58 @@ int upload_scene(rtiow_handle_s* h, int n, const T* cr, const T* af, const T* ri
     return 0;
 }
 
-// Builds the fp32 screening table of hit_world_screened for the current scene + camera:
-// centres recentred on the scene's centroid (ground-like spheres excluded), and
-// q' = |C'|^2 - r^2 - 2^-17 ((|C'| + Omax)^2 + r^2), rounded DOWN, pair-interleaved.
+// Builds the screening table of hit_world_screened for the current scene: centres recentred on
+// the scene's centroid (ground-like spheres excluded), q' = |C'|^2 - r^2 - 2^-17 (|C'|^2 + r^2)
+// rounded DOWN; fp32 pair-interleaved like geom_a, fp64 plain.  2 Cmax goes to the kernel for
+// the per-ray share of the margin.
+template <class T>
 int build_screen_table(rtiow_handle_s* h) {
     const int m = h->n, mp = h->n_padded;
-    const std::vector<float>& cr = h->host_cr;
+    const std::vector<double>& cr = h->host_cr;
     double ctr[3] = {0, 0, 0};
     int cnt = 0;
     for (int i = 0; i < m; ++i)
-        if (cr[4 * i + 3] < 100.0f) { for (int k = 0; k < 3; ++k) ctr[k] += cr[4 * i + k]; ++cnt; }
+        if (cr[4 * i + 3] < 100.0) { for (int k = 0; k < 3; ++k) ctr[k] += cr[4 * i + k]; ++cnt; }
     if (cnt) for (int k = 0; k < 3; ++k) ctr[k] /= cnt;
-    for (int k = 0; k < 3; ++k) h->ctr[k] = (float)ctr[k];
-    std::vector<float> lin((size_t)mp * 4);
+    for (int k = 0; k < 3; ++k) h->ctr[k] = (double)(T)ctr[k];
+    std::vector<T> lin((size_t)mp * 4);
     double cmax = 0;                                        // max |C'| over the spheres that are screened
     for (int i = 0; i < mp; ++i) {
-        if (i >= m) { lin[4 * i] = lin[4 * i + 1] = lin[4 * i + 2] = 0; lin[4 * i + 3] = 1e12f; continue; }   // padding: c~ huge => never a candidate
+        if (i >= m) { lin[4 * i] = lin[4 * i + 1] = lin[4 * i + 2] = 0; lin[4 * i + 3] = (T)1e12; continue; }   // padding: c~ huge => never a candidate
         double c2 = 0;
         for (int k = 0; k < 3; ++k) {
-            const float cp = (float)((double)cr[4 * i + k] - (double)h->ctr[k]);   // what the kernel will use as C'
+            const T cp = (T)(cr[4 * i + k] - h->ctr[k]);    // what the kernel will use as C'
             lin[4 * i + k] = cp;
             c2 += (double)cp * (double)cp;
         }
-        if (std::sqrt(c2) > 64.0) { lin[4 * i + 3] = -1e30f; continue; }           // e.g. the ground: always re-tested exactly
+        if (std::sqrt(c2) > 64.0) { lin[4 * i + 3] = (T)-1e30; continue; }         // e.g. the ground: always re-tested exactly
         cmax = std::max(cmax, std::sqrt(c2));
         const double r = cr[4 * i + 3], r2 = r * r;
         const double kappa = std::ldexp(1.0, -17) * (c2 + r2);                     // the sphere's share of the margin
-        float q = (float)(c2 - r2 - kappa);
-        if ((double)q > c2 - r2 - kappa) q = std::nextafterf(q, -INFINITY);
+        T q = (T)(c2 - r2 - kappa);
+        if ((double)q > c2 - r2 - kappa) q = std::nextafter(q, (T)-INFINITY);
         lin[4 * i + 3] = q;
     }
-    h->omax2 = (float)(2.0 * cmax * 1.0000001);            // per-ray share uses 2 Cmax |O'| + |O'|^2
-    std::vector<float> pi(lin.size());
-    for (int q = 0; q < mp / 2; ++q)
-        for (int k = 0; k < 4; ++k) { pi[8 * q + 2 * k] = lin[8 * q + k]; pi[8 * q + 2 * k + 1] = lin[8 * q + 4 + k]; }
+    h->omax2 = 2.0 * cmax * 1.0000001;                      // per-ray share uses 2 Cmax |O'| + |O'|^2
+    if (sizeof(T) == 4) {
+        std::vector<T> pi(lin.size());
+        for (int q = 0; q < mp / 2; ++q)
+            for (int k = 0; k < 4; ++k) { pi[8 * q + 2 * k] = lin[8 * q + k]; pi[8 * q + 2 * k + 1] = lin[8 * q + 4 + k]; }
+        lin.swap(pi);
+    }
     if (h->geom_s) { HIP_TRY(h, hipFree(h->geom_s)); h->geom_s = nullptr; }
-    HIP_TRY(h, hipMalloc((void**)&h->geom_s, pi.size() * sizeof(float)));
-    HIP_TRY(h, hipMemcpy(h->geom_s, pi.data(), pi.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMalloc(&h->geom_s, lin.size() * sizeof(T)));
+    HIP_TRY(h, hipMemcpy(h->geom_s, lin.data(), lin.size() * sizeof(T), hipMemcpyHostToDevice));
     h->screen_dirty = false;
     return 0;
 }
 
-template <class T> struct ScreenParams {
-    static void fill(RenderParams<T>& p, const rtiow_handle_s*) { p.geom_s = nullptr; p.use_screen = 0; p.ctr_x = p.ctr_y = p.ctr_z = 0; p.omax2 = 0; }
-};
-template <> struct ScreenParams<float> {
-    static void fill(RenderParams<float>& p, const rtiow_handle_s* h) {
-        p.geom_s = h->geom_s; p.use_screen = (h->scene_source == RTIOW_SCENE_LDS && h->geom_s) ? 1 : 0;
-        p.ctr_x = h->ctr[0]; p.ctr_y = h->ctr[1]; p.ctr_z = h->ctr[2]; p.omax2 = h->omax2;
-    }
-};
+template <class T>
+void fill_screen_params(RenderParams<T>& p, const rtiow_handle_s* h) {
+    p.geom_s = (const T*)h->geom_s;
+    p.use_screen = (h->scene_source == RTIOW_SCENE_LDS && h->geom_s) ? 1 : 0;
+    p.ctr_x = (T)h->ctr[0]; p.ctr_y = (T)h->ctr[1]; p.ctr_z = (T)h->ctr[2]; p.omax2 = (T)h->omax2;
+}
 
 template <class T> using RenderFn = void (*)(const RenderParams<T>);
 
@@ -1202,8 +1253,8 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     const bool persistent = h->schedule != RTIOW_SCHED_STATIC;
     const int threads = bx * by;
     const bool lds_source = h->scene_source != RTIOW_SCENE_SCALAR;
-    if (sizeof(T) == 4 && h->scene_source == RTIOW_SCENE_LDS && h->screen_dirty) { int rc = build_screen_table(h); if (rc) return rc; }
-    ScreenParams<T>::fill(p, h);
+    if (h->scene_source == RTIOW_SCENE_LDS && h->screen_dirty) { int rc = build_screen_table<T>(h); if (rc) return rc; }
+    fill_screen_params<T>(p, h);
     size_t lds = lds_source ? sizeof(T) * 4 * (size_t)h->n_padded : 0;
     p.screen_offset = (int)lds;
     if (p.use_screen) lds += sizeof(T) * 4 * (size_t)h->n_padded;
@@ -1389,7 +1440,6 @@ int rtiow_set_camera(rtiow_handle h, const void* camera) {
     else { h->cam64 = *(const rtiow_camera_f64*)camera; W = h->cam64.img_width; H = h->cam64.img_height; S = h->cam64.samples_per_pixel; }
     if (W <= 0 || H <= 0 || S < 0 || (int64_t)W * H > 0x7fffffffLL) { h->have_camera = false; return fail_arg(h, RTIOW_E_BADARG, "rtiow_set_camera: bad image size"); }
     h->have_camera = true;
-    h->screen_dirty = true;
     h->local_rows = compute_local_rows(H, h->rank, h->nranks, h->strip_rows);
     h->stats.local_rows = h->local_rows;
     h->rng_ready = false;

@@ -34,4 +34,4 @@ if __name__ == "__main__":
     main(3, shard=(3, 8, 8), variants=[(2, 0, 2, 0), (0, 0, 2, 0)])
     main(3, shard=(1, 2, 8), variants=[(2, 0, 2, 0), (0, 0, 2, 0)])
     main(1, rounds=3, variants=[(2, 0, 1, 0), (0, 0, 1, 0), (2, 0, 2, 0), (0, 0, 2, 0)])
-    main(3, prec=64, rounds=3, variants=[(0, 0, 1, 0), (0, 0, 2, 0)])
+    main(3, prec=64, rounds=3, variants=[(2, 0, 2, 0), (0, 0, 2, 0), (0, 0, 1, 0)])

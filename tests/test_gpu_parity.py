@@ -257,6 +257,16 @@ def test_screen_equals_exact_on_the_488_sphere_scene(rt):
     assert _same_bits(a, b)
 
 
+def test_screen_equals_exact_fp64(rt, oracle):
+    """fp64 screen vs the exact loop on a mid-size frame, and both against oracle rows."""
+    W, H, S, B = 640, 360, 20, 50
+    a = _render(rt, 64, 3, W, H, S, B, threads=0)
+    b = _render(rt, 64, 3, W, H, S, B, threads=0, source=rt.SCENE_LDS_EXACT, sched=rt.SCHED_STATIC)
+    assert _same_bits(a, b)
+    want, _ = _oracle(oracle, rt, 64, 3, W, H, S, B, rows=(200, 202))
+    assert _same_bits(a[200:202], want)
+
+
 def test_full_size_properties(rt, oracle):
     """BASELINE headline config (scene 3, 1920x1080, 100 spp, 50 bounces): too big for the
     oracle in full, so: (1) run-to-run determinism, (2) 8-way sharded == whole image,
