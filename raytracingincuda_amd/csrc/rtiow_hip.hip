@@ -593,6 +593,59 @@ __device__ __forceinline__ bool segment_step(const RenderParams<T>& p, const T* 
     return shade_step<T>(p, lds_shade, st, closest, hit, col);
 }
 
+// ---- the last stage of the drain: ONE ray left in a full wave.  The ray is broadcast with
+// v_readlane (no LDS round trip), every lane takes one 4-sphere trip, and the 64 partial hits are
+// reduced as one 64-bit key {t bits, index} -- t > 0 or +inf, so the IEEE bits order like the
+// values and the key minimum is the lexicographic (t, index) minimum of the exact loop -- with DPP
+// row operations (register-to-register) plus four readlanes, instead of 14 ds_bpermute round trips.
+template <int CTRL> __device__ __forceinline__ unsigned dpp_mov(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL> __device__ __forceinline__ void key_min_step(unsigned& hi, unsigned& lo) {
+    const unsigned ohi = dpp_mov<CTRL>(hi), olo = dpp_mov<CTRL>(lo);
+    const bool take = (ohi < hi) || (ohi == hi && olo < lo);
+    hi = take ? ohi : hi;
+    lo = take ? olo : lo;
+}
+__device__ __forceinline__ unsigned long long wave_min_key(unsigned hi, unsigned lo) {
+    key_min_step<0xB1>(hi, lo);      // quad_perm [1,0,3,2]  : lane ^ 1
+    key_min_step<0x4E>(hi, lo);      // quad_perm [2,3,0,1]  : lane ^ 2
+    key_min_step<0x141>(hi, lo);     // row_half_mirror      : across the quads of a half row
+    key_min_step<0x140>(hi, lo);     // row_mirror           : across the half rows -> every lane of a 16-lane row holds the row minimum
+    unsigned long long best = ~0ull;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const unsigned long long k = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, row * 16) << 32) |
+                                     (unsigned)__builtin_amdgcn_readlane((int)lo, row * 16);
+        best = k < best ? k : best;
+    }
+    return best;
+}
+
+template <int SRC>
+__device__ __forceinline__ void hit_world_solo(const RenderParams<float>& p, const float* lds_geom, int owner, bool is_owner,
+                                               V3<float> O, V3<float> D, float a, float& closest, int& hit) {
+    auto bcast = [owner](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), owner)); };
+    const float ox = bcast(O.x), oy = bcast(O.y), oz = bcast(O.z);
+    const float dx = bcast(D.x), dy = bcast(D.y), dz = bcast(D.z);
+    const float ra = bcast(a);
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const float* gm = (SRC == RTIOW_SCENE_LDS) ? lds_geom : p.geom_a;
+    const LoopRay<float> r = make_loop_ray(ox, oy, oz, dx, dy, dz, ra);
+    float best = __builtin_huge_valf();
+    int best_idx = -1;
+    for (int s = lane * 4; s < p.n_padded; s += 256) sphere_trip<float>(gm, s, r, best, best_idx);
+    const unsigned long long k = wave_min_key(__float_as_uint(best), (unsigned)best_idx);
+    if (is_owner) { closest = __uint_as_float((unsigned)(k >> 32)); hit = (int)(unsigned)k; }
+}
+
+template <int SRC>
+__device__ __forceinline__ void coop_solo(const RenderParams<float>& p, const float* g, int owner, bool is_owner, V3<float> O, V3<float> D, float a, float& closest, int& hit) {
+    hit_world_solo<SRC>(p, g, owner, is_owner, O, D, a, closest, hit);
+}
+template <int SRC>
+__device__ __forceinline__ void coop_solo(const RenderParams<double>&, const double*, int, bool, V3<double>, V3<double>, double, double&, int&) {}
+
 // ---- cooperative hit_world for the drain tail of the persistent kernel.
 // When the work pool is empty and n <= 32 lanes of a wave still carry a path, the wave's
 // idle lanes help: the n rays are published in LDS, each ray is served by a group of
@@ -861,7 +914,10 @@ render_persistent_kernel(const RenderParams<T> p) {
             int hit = -1;
             if (hit_mask != 0) {
                 const T a = dot3(st.D, st.D);
-                hit_world_coop<T, SRC>(p, lds_geom, coop_slots, need_hit, hit_mask, __builtin_popcountll(hit_mask), wave_lanes, st.O, st.D, a, closest, hit);
+                if (sizeof(T) == 4 && wave_lanes == 64 && (hit_mask & (hit_mask - 1)) == 0)
+                    coop_solo<SRC>(p, lds_geom, (int)__builtin_ctzll(hit_mask), need_hit, st.O, st.D, a, closest, hit);
+                else
+                    hit_world_coop<T, SRC>(p, lds_geom, coop_slots, need_hit, hit_mask, __builtin_popcountll(hit_mask), wave_lanes, st.O, st.D, a, closest, hit);
             }
             if (alive) {
                 if (need_hit) { ++cost; if (COUNT) ++nseg; }
