@@ -267,6 +267,42 @@ def test_screen_equals_exact_fp64(rt, oracle):
     assert _same_bits(a[200:202], want)
 
 
+def test_baseline_config3_1280x720(rt, oracle):
+    """BASELINE configs[2]: scene 3, 1280x720, 100 spp, 50 bounces -- oracle rows + shard invariance."""
+    W, H, S, B = 1280, 720, 100, 50
+    a = _render(rt, 32, 3, W, H, S, B, threads=8)
+    for row in (5, 400, 719):
+        want, _ = _oracle(oracle, rt, 32, 3, W, H, S, B, rows=(row, row + 1))
+        assert _same_bits(a[row:row + 1], want), row
+    full = np.zeros_like(a)
+    for rank in range(2):
+        rt.place_rows(full, _render(rt, 32, 3, W, H, S, B, threads=0, shard=(rank, 2, 8)), rank, 2, 8)
+    assert _same_bits(full, a)
+
+
+def test_baseline_config5_fp64_500spp_and_float_vs_double(rt, oracle, tmp_path):
+    """BASELINE configs[4]: fp64, scene 3, 1920x1080, 500 spp, 50 bounces.  Oracle row spot check,
+    and the reference's own acceptance procedure (README.md:101-116): ppm_diff of the float and the
+    double image must be 'rather dark' -- here quantified against the calibrated noise floor of
+    SURVEY A.5 (two independent 100-spp renders differ by mean 1.41 levels; at 500 spp ~0.63)."""
+    W, H, S, B = 1920, 1080, 500, 50
+    d = _render(rt, 64, 3, W, H, S, B, threads=0)
+    assert np.isfinite(d).all() and d.min() >= 0
+    want, _ = _oracle(oracle, rt, 64, 3, W, H, S, B, rows=(700, 701))
+    assert _same_bits(d[700:701], want)
+    f = _render(rt, 32, 3, W, H, S, B, threads=0)
+    pf, pd = str(tmp_path / "f.ppm"), str(tmp_path / "d.ppm")
+    rt.write_ppm(pf, f); rt.write_ppm(pd, d)
+    exe = os.path.join(os.path.dirname(rt.lib_paths()["hip"]), "..", "bin", "ppm_diff")
+    r = subprocess.run([exe, pf, pd, str(tmp_path / "diff.ppm"), "--max-mean", "1.0", "--max-p99", "8"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    lf = np.floor(256 * np.clip(f.astype(np.float64), 0, 0.999)); ld = np.floor(256 * np.clip(d, 0, 0.999))
+    # per-channel bias: fp32 comes out ~0.33 levels (0.2 %) darker than fp64 -- the algorithm's own
+    # precision effect (fp32 self-intersections at tmin against the radius-1000 ground sphere), the
+    # bit-exact oracle shows the same; anything beyond a fraction of a level would be a bug
+    assert np.all(np.abs(lf.mean(axis=(0, 1)) - ld.mean(axis=(0, 1))) < 0.6)
+
+
 def test_full_size_properties(rt, oracle):
     """BASELINE headline config (scene 3, 1920x1080, 100 spp, 50 bounces): too big for the
     oracle in full, so: (1) run-to-run determinism, (2) 8-way sharded == whole image,
