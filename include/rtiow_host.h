@@ -44,6 +44,9 @@ int rtiow_host_ppm_filename(int precision, int scene_id, int width, int height, 
  * rtiow_host_format_ppm writes into memory (returns the length needed via *len). */
 int rtiow_host_write_ppm(const char* path, int precision, int width, int height, const void* rgb);
 int rtiow_host_format_ppm(int precision, int width, int height, const void* rgb, char* out, size_t cap, size_t* len);
+/* Binary variant (not in the reference): "P6\nW H\n255\n" + one byte per channel, the same
+ * int(256*clamp(c, 0.000, 0.999)) levels; ~12x smaller and faster than the text file. */
+int rtiow_host_write_ppm_binary(const char* path, int precision, int width, int height, const void* rgb);
 
 /* Row sharding used by rtiow_set_shard (rtiow.h): strips of strip_rows rows dealt round-robin.
  * Writes the global row index of every local row of `rank` (rows_out may be NULL) and returns

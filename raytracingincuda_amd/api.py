@@ -73,7 +73,7 @@ HIP_SYMBOLS = [
 ]
 HOST_SYMBOLS = [
     "rtiow_host_scene_slots", "rtiow_host_build_scene", "rtiow_host_camera", "rtiow_host_ppm_filename",
-    "rtiow_host_write_ppm", "rtiow_host_format_ppm", "rtiow_host_shard_rows", "rtiow_host_place_rows",
+    "rtiow_host_write_ppm", "rtiow_host_format_ppm", "rtiow_host_write_ppm_binary", "rtiow_host_shard_rows", "rtiow_host_place_rows",
 ]
 
 _hip = None
@@ -97,6 +97,7 @@ def load_host_library():
         lib.rtiow_host_camera.argtypes = [ctypes.c_int] * 5 + [vp]
         lib.rtiow_host_ppm_filename.argtypes = [ctypes.c_int] * 7 + [ctypes.c_char_p, ctypes.c_size_t]
         lib.rtiow_host_write_ppm.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+        lib.rtiow_host_write_ppm_binary.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
         lib.rtiow_host_format_ppm.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_char_p,
                                               ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
         lib.rtiow_host_shard_rows.argtypes = [ctypes.c_int] * 4 + [i32p]
@@ -225,9 +226,12 @@ def format_ppm(rgb):
     return buf.raw[:n.value]
 
 
-def write_ppm(path, rgb):
+def write_ppm(path, rgb, binary=False):
+    """P3 text file exactly as main.cu:368-379 writes it; binary=True writes the P6 twin (same levels)."""
     rgb = np.ascontiguousarray(rgb)
-    rc = load_host_library().rtiow_host_write_ppm(os.fsencode(path), _rgb_precision(rgb), rgb.shape[1], rgb.shape[0], rgb.ctypes.data)
+    lib = load_host_library()
+    fn = lib.rtiow_host_write_ppm_binary if binary else lib.rtiow_host_write_ppm
+    rc = fn(os.fsencode(path), _rgb_precision(rgb), rgb.shape[1], rgb.shape[0], rgb.ctypes.data)
     if rc:
         raise RtiowError(rc, "Could not open file for writing: %s" % path)
 

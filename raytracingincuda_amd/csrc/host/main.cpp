@@ -28,6 +28,7 @@ struct Options {
     int scene_id = 0, width = 320, height = 192, samples = 10, bounces = 25, threads = 8;   // main.cu:45-54
     int scene_source = RTIOW_SCENE_LDS;
     bool stats = false;
+    bool binary_ppm = false;
 };
 
 const char* kUsage =
@@ -70,7 +71,7 @@ Options parse(int argc, char** argv) {
         if (eq != std::string::npos) { value = name.substr(eq + 1); name = name.substr(0, eq); have_value = true; }
         if (name == "stats") { o.stats = true; continue; }
         const bool known = name == "scene_id" || name == "width" || name == "height" || name == "samples" ||
-                           name == "bounces" || name == "threads" || name == "scene_source";
+                           name == "bounces" || name == "threads" || name == "scene_source" || name == "ppm_format";
         if (!known) parse_abort("Option '" + name + "' does not exist");
         if (!have_value) {
             if (k + 1 >= argc) parse_abort("Option '" + name + "' is missing an argument");
@@ -79,6 +80,12 @@ Options parse(int argc, char** argv) {
         if (name == "scene_source") {
             if (value == "lds") o.scene_source = RTIOW_SCENE_LDS;
             else if (value == "scalar") o.scene_source = RTIOW_SCENE_SCALAR;
+            else parse_abort("Argument '" + value + "' failed to parse");
+            continue;
+        }
+        if (name == "ppm_format") {
+            if (value == "p3") o.binary_ppm = false;
+            else if (value == "p6") o.binary_ppm = true;
             else parse_abort("Argument '" + value + "' failed to parse");
             continue;
         }
@@ -149,7 +156,9 @@ int main(int argc, char** argv) {
     rtiow_host_ppm_filename(precision, opt.scene_id, opt.width, opt.height, opt.samples, opt.bounces, opt.threads, name, sizeof name);
     std::vector<unsigned char> rgb(elem * 3 * (size_t)opt.width * opt.height);
     check(h, rtiow_read_framebuffer(h, rgb.data(), rgb.size()));
-    if (rtiow_host_write_ppm(name, precision, opt.width, opt.height, rgb.data()) != 0) {
+    const int wrc = opt.binary_ppm ? rtiow_host_write_ppm_binary(name, precision, opt.width, opt.height, rgb.data())
+                                   : rtiow_host_write_ppm(name, precision, opt.width, opt.height, rgb.data());
+    if (wrc != 0) {
         std::fprintf(stderr, "Error: Could not open file for writing: %s\n", name);
         return -1;
     }

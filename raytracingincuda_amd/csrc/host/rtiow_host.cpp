@@ -232,6 +232,24 @@ int rtiow_host_write_ppm(const char* path, int precision, int width, int height,
     return (std::fclose(f) == 0 && ok) ? 0 : RTIOW_E_STATE;
 }
 
+// Binary twin of the P3 writer: "P6\nW H\n255\n" + 3 bytes per pixel, same quantisation
+// (the text writer dominates end-to-end time minus render).
+int rtiow_host_write_ppm_binary(const char* path, int precision, int width, int height, const void* rgb) {
+    if (!path || !rgb || width <= 0 || height <= 0 || (precision != 32 && precision != 64)) return RTIOW_E_BADARG;
+    char head[64];
+    const int hn = std::snprintf(head, sizeof head, "P6\n%d %d\n255\n", width, height);
+    const size_t n = (size_t)width * height * 3;
+    std::string s(head, (size_t)hn);
+    s.resize((size_t)hn + n);
+    unsigned char* out = reinterpret_cast<unsigned char*>(&s[(size_t)hn]);
+    if (precision == 32) { const float* v = (const float*)rgb; for (size_t k = 0; k < n; ++k) out[k] = (unsigned char)to_level<float>(v[k]); }
+    else { const double* v = (const double*)rgb; for (size_t k = 0; k < n; ++k) out[k] = (unsigned char)to_level<double>(v[k]); }
+    std::FILE* f = std::fopen(path, "wb");
+    if (!f) return RTIOW_E_STATE;
+    const bool ok = std::fwrite(s.data(), 1, s.size(), f) == s.size();
+    return (std::fclose(f) == 0 && ok) ? 0 : RTIOW_E_STATE;
+}
+
 int rtiow_host_shard_rows(int height, int rank, int nranks, int strip_rows, int32_t* rows_out) {
     if (height <= 0 || nranks < 1 || rank < 0 || rank >= nranks || strip_rows < 1) return RTIOW_E_BADARG;
     const int nstrips = (height + strip_rows - 1) / strip_rows;

@@ -225,6 +225,16 @@ def test_executable_is_a_drop_in(rt, oracle, tmp_path):
     assert os.listdir(str(tmp_path)) == [name]
     want, _ = _oracle(oracle, rt, 32, 1, 160, 96, 4, 25)
     assert open(str(tmp_path / name), "rb").read() == rt.format_ppm(want)
+    # optional binary output: same file name, P6, same levels (ppm_diff of the two is all zeros)
+    sub = tmp_path / "p6"; sub.mkdir()
+    r6 = subprocess.run([exe, "--scene_id", "1", "--width=160", "--height", "96", "--samples", "4", "--bounces=25", "--threads", "8",
+                         "--ppm_format", "p6"], capture_output=True, text=True, cwd=str(sub))
+    assert r6.returncode == 0, r6.stderr
+    raw = open(str(sub / name), "rb").read()
+    assert raw.startswith(b"P6\n160 96\n255\n") and len(raw) == 14 + 160 * 96 * 3
+    levels = np.array(rt.format_ppm(want).split()[4:], dtype=np.uint8)
+    assert np.array_equal(np.frombuffer(raw[14:], np.uint8), levels)
+    (tmp_path / "p6" / name).unlink(); sub.rmdir()
     # defaults (main.cu:45-54) and the double variant's name (GlobalDouble main.cu:351)
     exe64 = exe.replace("float", "double")
     r = subprocess.run([exe64, "--scene_id=3", "--samples=1", "--bounces=2"], capture_output=True, text=True, cwd=str(tmp_path))

@@ -92,6 +92,9 @@ def test_ppm_writer_semantics(native, tmp_path, oracle):
         path = str(tmp_path / "x.ppm")
         native.write_ppm(path, img)
         assert open(path, "rb").read() == text
+        # binary twin: same levels, one byte per channel; ppm_diff reads both as equal
+        native.write_ppm(path + "6", img, binary=True)
+        assert open(path + "6", "rb").read() == b"P6\n2 2\n255\n" + bytes([0, 128, 255, 255, 255, 0, 255, 0, 64, 1, 0, 179])
     # same quantisation as the reference serial writer on a real image (color.h:40-43)
     p3, _ = oracle.render_serial(3, 32, 18, 2, 5)
     vals = np.array(p3.split()[4:], np.int64)
