@@ -81,7 +81,9 @@ _host = None
 
 
 def lib_paths():
-    return {"hip": os.path.join(_LIBDIR, "librtiow_hip.so"), "host": os.path.join(_LIBDIR, "librtiow_host.so")}
+    # RTIOW_HIP_LIBRARY: another build of the same C-ABI (A/B timing of kernel variants, the stats build)
+    return {"hip": os.environ.get("RTIOW_HIP_LIBRARY") or os.path.join(_LIBDIR, "librtiow_hip.so"),
+            "host": os.path.join(_LIBDIR, "librtiow_host.so")}
 
 
 def load_host_library():

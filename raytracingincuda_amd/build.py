@@ -49,6 +49,15 @@ def _run(cmd, verbose):
     subprocess.run(cmd, check=True)
 
 
+def build_stats(verbose=True):
+    """Optional: the HIP library with the execution-profile counters compiled in
+    (lib/librtiow_hip_stats.so, -DRTIOW_PATH_STATS; used by scripts/path_stats_probe.py only)."""
+    os.makedirs(LIB, exist_ok=True)
+    out = os.path.join(LIB, "librtiow_hip_stats.so")
+    _run([_hipcc()] + HIP_FLAGS + ["-DRTIOW_PATH_STATS", "-o", out, os.path.join(CSRC, "rtiow_hip.hip")], verbose)
+    return out
+
+
 def build(force=False, verbose=True):
     os.makedirs(LIB, exist_ok=True)
     os.makedirs(BIN, exist_ok=True)
@@ -96,3 +105,5 @@ def build(force=False, verbose=True):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    if "--stats" in sys.argv:
+        build_stats()

@@ -196,12 +196,36 @@ template <class T> __device__ __forceinline__ V3<T> reflect3(V3<T> v, V3<T> n) {
     T k = (T)2 * dot3(v, n);
     return madd3(-k, n, v);
 }
+// ---- optional execution profile (build with -DRTIOW_PATH_STATS, `python -m raytracingincuda_amd.build
+// --stats`): per region, how many times a WAVE executed it and with how many active lanes.  The
+// kernel is bound by the vector instructions it issues, and a divergent region costs its full
+// instruction count whenever one lane needs it, so (wave executions x static instruction count)
+// is the time budget (scripts/path_stats_probe.py).  Compiled out by default.
+#ifdef RTIOW_PATH_STATS
+enum { PS_ITERATION = 0, PS_RUV_CALL, PS_RUV_ROUND, PS_DISK_ROUND, PS_GEN_PRIMARY, PS_SHADE_HIT, PS_SKY, PS_DIELECTRIC, PS_METAL,
+       PS_EXACT_BLOCK, PS_FINISH_CALL, PS_IEEE_BLOCK, PS_SECOND_DIV, PS_SCHLICK_DRAW, PS_REFILL, PS_FINISH_PIXEL, PS_COUNT };
+__device__ unsigned long long g_path_stats[2 * PS_COUNT];
+__device__ __forceinline__ void path_stat(int region) {
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (lane == __builtin_ctzll(act)) {
+        atomicAdd(&g_path_stats[2 * region], 1ull);
+        atomicAdd(&g_path_stats[2 * region + 1], (unsigned long long)__builtin_popcountll(act));
+    }
+}
+#define PATH_STAT(r) path_stat(r)
+#else
+#define PATH_STAT(r) ((void)0)
+#endif
+
 template <class T> __device__ __forceinline__ V3<T> random_unit_vector(Rng& s) {   // vec3.h:117-127
     // The rejection loop only finds the accepted candidate; its normalisation (an IEEE sqrt and
     // divide, ~30 instructions) runs once after the loop instead of in every round the wave
     // executes for its slowest lane.  Same draws, same arithmetic on the accepted candidate.
     T x, y, z, lensq;
+    PATH_STAT(PS_RUV_CALL);
     for (;;) {
+        PATH_STAT(PS_RUV_ROUND);
         x = RT_FMA(Real<T>::uniform(s), (T)2, (T)-1);
         y = RT_FMA(Real<T>::uniform(s), (T)2, (T)-1);
         z = RT_FMA(Real<T>::uniform(s), (T)2, (T)-1);
@@ -217,6 +241,7 @@ template <class T> __device__ __forceinline__ V3<T> random_unit_vector(Rng& s) {
 template <class T>
 __device__ __forceinline__ void gen_primary(const RenderParams<T>& p, int i, int j, Rng& s,
                                             V3<T>& O, V3<T>& D, T& sky_uy) {
+    PATH_STAT(PS_GEN_PRIMARY);
     T ox = Real<T>::uniform(s) - (T)0.5;
     T oy = Real<T>::uniform(s) - (T)0.5;
     T fi = (T)i + ox, fj = (T)j + oy;
@@ -225,6 +250,7 @@ __device__ __forceinline__ void gen_primary(const RenderParams<T>& p, int i, int
     if (!(p.defocus_angle <= (T)0)) {
         T px, py;
         for (;;) {
+            PATH_STAT(PS_DISK_ROUND);
             px = RT_FMA((T)2, Real<T>::uniform(s), (T)-1);
             py = RT_FMA((T)2, Real<T>::uniform(s), (T)-1);
             if (RT_FMA(py, py, px * px) < (T)1) break;
@@ -249,25 +275,33 @@ __device__ __forceinline__ double fast_sqrt(double x) { return __builtin_amdgcn_
 // pre-test drops a sphere ONLY when the exact code below provably would: all roots of one ray
 // share the divisor a > 0, so they order like their numerators n = h -+ sqrt(disc);
 //   (behind) n2 + e <  tmin*a*(1-2^-20)  =>  both exact roots <= tmin;
-//   (far)    n1 - e >  closest*a*(1+2^-20) =>  exact near root >= closest, hence the far one too;
-// with e = 2^-20 (|h| + sqrt) covering the raw sqrt's error (2^-22) and every rounding involved
-// (2^-23 each) four times over.  In doubt the exact code runs, so the result is unchanged.
+//   (far)    n1 - e >  closest*a*(1+2^-20) =>  exact near root >= closest, hence the far one too.
+// e bounds |n_fast - n_ref|: the raw sqrt is within 1 ulp (2^-23 relative) and the reference's
+// IEEE sqrt within half an ulp, so the two square roots differ by at most 0.75 * 2^-22 * sqrt;
+// the additions h -+ sqrt round once on each side (2^-24 |n| each, |n| <= |h| + sqrt).  Hence
+// e = 2^-22 (|h| + sqrt) + 2^-60 (the constant covers a raw sqrt that flushes a denormal
+// discriminant to zero).  Rays leaving the ground sphere (|h|, sqrt ~ 1000, far root = rounding
+// noise ~1e-4) are what the tight bound is for: with 2^-20 every one of them fell through to
+// the IEEE code.  In doubt the exact code runs, so the result is unchanged.
 template <class T>
 __device__ __forceinline__ void finish_sphere_test(int s, T h, T disc, T a, T& closest, int& hit) {
     const T tmin = (T)0.001;
+    PATH_STAT(PS_FINISH_CALL);
     {
-        const T kappa = (T)9.5367431640625e-07;                        // 2^-20
+        const T kappa = (T)2.384185791015625e-07;                      // 2^-22
         const T sq_approx = fast_sqrt(disc);
-        const T e = kappa * (Real<T>::fabs(h) + sq_approx);
+        const T e = RT_FMA(kappa, Real<T>::fabs(h) + sq_approx, (T)8.673617379884035e-19);   // + 2^-60
         const T behind_bound = (tmin * a) * (T)0.99999904632568359375;  // tmin*a*(1-2^-20)
         const T far_bound = (closest * a) * (T)1.00000095367431640625; // closest*a*(1+2^-20); inf while nothing is hit
         if ((h + sq_approx) + e < behind_bound) return;
         if ((h - sq_approx) - e > far_bound) return;
     }
+    PATH_STAT(PS_IEEE_BLOCK);
     const T sq = Real<T>::sqrt(disc);                               // :50
     T root = (h - sq) / a;                                          // :53
     bool ok = (tmin < root) && (root < closest);                    // :54
     if (!ok) {
+        PATH_STAT(PS_SECOND_DIV);
         root = (h + sq) / a;                                        // :55
         ok = (tmin < root) && (root < closest);                     // :56
     }
@@ -367,6 +401,7 @@ __device__ __forceinline__ void hit_world_direct(const RenderParams<T>& p, const
 // hit_sphere for ONE sphere, scalar, exactly the reference's arithmetic (used by the screened
 // loop for its rare candidates; the table is the pair-interleaved fp32 one).
 __device__ __forceinline__ void exact_sphere_test_f32(const float* g, int s, V3<float> O, V3<float> D, float a, float& closest, int& hit) {
+    PATH_STAT(PS_EXACT_BLOCK);
     const int base = (s >> 1) * 8 + (s & 1);
     const float cx = g[base], cy = g[base + 2], cz = g[base + 4], r2 = g[base + 6];
     const float ocx = cx - O.x, ocy = cy - O.y, ocz = cz - O.z;                                   // :42
@@ -403,7 +438,7 @@ __device__ __forceinline__ void hit_world_screened(const RenderParams<float>& p,
     float dx = D.x * rs, dy = D.y * rs, dz = D.z * rs;
     float nk1 = -__builtin_fmaf(dz, oz, __builtin_fmaf(dy, oy, dx * ox));
     float k2 = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
-    k2 = k2 - 7.62939453125e-06f * __builtin_fmaf(p.omax2, __builtin_sqrtf(k2), k2);   // - 2^-17 (2 Cmax |O'| + |O'|^2); p.omax2 holds 2 Cmax
+    k2 = k2 - 7.62939453125e-06f * __builtin_fmaf(p.omax2, fast_sqrt(k2), k2);   // - 2^-17 (2 Cmax |O'| + |O'|^2); p.omax2 holds 2 Cmax (1 + 2^-20): raw sqrt
     float mx = -2.0f * ox, my = -2.0f * oy, mz = -2.0f * oz;
     asm volatile("" : "+v"(nk1), "+v"(k2), "+v"(mx), "+v"(my), "+v"(mz), "+v"(dx), "+v"(dy), "+v"(dz));
     const v2f vnk1 = {nk1, nk1}, vk2 = {k2, k2}, vmx = {mx, mx}, vmy = {my, my}, vmz = {mz, mz};
@@ -450,7 +485,7 @@ __device__ __forceinline__ void hit_world_screened(const RenderParams<double>& p
     const double dx = D.x * rs, dy = D.y * rs, dz = D.z * rs;
     const double nk1 = -__builtin_fma(dz, oz, __builtin_fma(dy, oy, dx * ox));
     double k2 = __builtin_fma(oz, oz, __builtin_fma(oy, oy, ox * ox));
-    k2 = k2 - 7.62939453125e-06 * __builtin_fma(p.omax2, __builtin_sqrt(k2), k2);
+    k2 = k2 - 7.62939453125e-06 * __builtin_fma(p.omax2, fast_sqrt(k2), k2);
     const double mx = -2.0 * ox, my = -2.0 * oy, mz = -2.0 * oz;
     for (int s = 0; s < p.n_padded; s += 4) {
         double dsc[4];
@@ -511,6 +546,7 @@ __device__ __forceinline__ bool shade_step(const RenderParams<T>& p, const T* ld
     col = {0, 0, 0};
     const V3<T> O = st.O, D = st.D;
     if (hit < 0) {
+        PATH_STAT(PS_SKY);
         // ------------ sky, from the PRIMARY ray (camera.h:120-124)
         const double a_sky = 0.5 * ((double)st.sky_uy + 1.0);
         const T w1 = (T)(1.0 - a_sky), w2 = (T)a_sky;
@@ -521,6 +557,7 @@ __device__ __forceinline__ bool shade_step(const RenderParams<T>& p, const T* ld
     // ------------ complete the hit record (hittable.h:59-63, :21-26)
     // one 12-word record per sphere; LDS copy when it fits (no global-load latency on the
     // critical path of the drain tail), else through L1/L2
+    PATH_STAT(PS_SHADE_HIT);
     T rec[12];
     if (p.shade_in_lds) {
 #pragma unroll
@@ -540,6 +577,7 @@ __device__ __forceinline__ bool shade_step(const RenderParams<T>& p, const T* ld
     V3<T> att = {rec[4], rec[5], rec[6]};
     bool ok = true;
     if (mtype == RTIOW_DIELECTRIC) {                                     // material.h:68-89
+        PATH_STAT(PS_DIELECTRIC);
         att = {1, 1, 1};
         const T ri = front ? rec[9] : rec[8];
         const V3<T> ud = unit3(D);
@@ -552,6 +590,7 @@ __device__ __forceinline__ bool shade_step(const RenderParams<T>& p, const T* ld
             const float x = (float)((T)1 - cos_theta);
             const float x2 = x * x;
             const float p5 = (x2 * x2) * x;                              // powf(x,5), see DESIGN.md
+            PATH_STAT(PS_SCHLICK_DRAW);
             const T refl = RT_FMA((T)1 - r0, (T)p5, r0);
             reflect_it = refl > Real<T>::uniform(st.rs);
         }
@@ -569,6 +608,7 @@ __device__ __forceinline__ bool shade_step(const RenderParams<T>& p, const T* ld
             const T e = Real<T>::near_zero;
             if (Real<T>::fabs(nd.x) < e && Real<T>::fabs(nd.y) < e && Real<T>::fabs(nd.z) < e) nd = nrm;
         } else {                                                         // material.h:51-59
+            PATH_STAT(PS_METAL);
             const V3<T> ur = unit3(reflect3(D, nrm));
             nd = madd3(rec[7], ruv, ur);
             ok = dot3(nd, nrm) > (T)0;
@@ -846,6 +886,7 @@ render_persistent_kernel(const RenderParams<T> p) {
     for (;;) {
         if (!exhausted && __builtin_amdgcn_ballot_w64(!alive) != 0) {
             bool want = !alive;
+            PATH_STAT(PS_REFILL);
             for (;;) {
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
                 if (m == 0) break;
@@ -901,6 +942,7 @@ render_persistent_kernel(const RenderParams<T> p) {
         }
         const unsigned long long alive_mask = __builtin_amdgcn_ballot_w64(alive);
         if (alive_mask == 0) break;
+        if (alive) PATH_STAT(PS_ITERATION);
         // one site generates every primary ray: first sample of a new pixel or the next sample
         if (alive && fresh) { gen_primary(p, i, j, st.rs, st.O, st.D, st.sky_uy); st.atten = {1, 1, 1}; fresh = false; }
         bool terminated = false;
@@ -935,7 +977,7 @@ render_persistent_kernel(const RenderParams<T> p) {
             ++st.sample;
             st.depth = 0;
             if (st.sample < S) fresh = true;
-            else { finish_pixel(p, lp, npix, st, cost); alive = false; }
+            else { PATH_STAT(PS_FINISH_PIXEL); finish_pixel(p, lp, npix, st, cost); alive = false; }
         }
     }
     if (COUNT) {
@@ -1259,7 +1301,7 @@ int build_screen_table(rtiow_handle_s* h) {
         if ((double)q > c2 - r2 - kappa) q = std::nextafter(q, (T)-INFINITY);
         lin[4 * i + 3] = q;
     }
-    h->omax2 = 2.0 * cmax * 1.0000001;                      // per-ray share uses 2 Cmax |O'| + |O'|^2
+    h->omax2 = 2.0 * cmax * 1.000001;                       // per-ray share uses 2 Cmax |O'| + |O'|^2; the slack covers the raw sqrt (<= 2^-22 relative) in the kernel
     if (sizeof(T) == 4) {
         std::vector<T> pi(lin.size());
         for (int q = 0; q < mp / 2; ++q)
@@ -1428,6 +1470,15 @@ void block_shape(int T, int& bx, int& by, int& wave_tiles) {
 extern "C" {
 
 int rtiow_abi_version(void) { return RTIOW_ABI_VERSION; }
+
+#ifdef RTIOW_PATH_STATS
+// stats build only: read (reset != 0: clear) the execution profile, 2 words per region
+int rtiow_debug_path_stats(unsigned long long* out, int cap_words, int reset) {
+    if (reset) { unsigned long long z[2 * PS_COUNT] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_path_stats), z, sizeof z); }
+    if (!out || cap_words < 2 * PS_COUNT) return RTIOW_E_BADARG;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_path_stats), 2 * PS_COUNT * sizeof(unsigned long long));
+}
+#endif
 
 int rtiow_create(int device, int precision, rtiow_handle* out) {
     if (!out || (precision != 32 && precision != 64)) return RTIOW_E_BADARG;
