@@ -149,7 +149,7 @@ template <class T> struct RenderParams {
     const T* __restrict__ geom_a;     // [n_padded][4] cx,cy,cz,r*r (sphere loop; padding never hits)
     // fp32 screening table (hit_world_screened): recentred centres and q' = |C'|^2 - r^2 - margin,
     // pair-interleaved like geom_a; staged in LDS behind geom_a (screen_offset bytes)
-    const T* __restrict__ geom_s;
+    const float* __restrict__ geom_s;
     int use_screen, screen_offset;
     T ctr_x, ctr_y, ctr_z, omax2;     // recentring point; omax2 = 2 Cmax of the per-ray margin term
     // everything the shade step needs about the sphere that was hit, 12 T per sphere:
@@ -431,14 +431,39 @@ __device__ __forceinline__ void exact_sphere_test_f32(const float* g, int s, V3<
 // and is skipped like there; every other sphere is re-tested with the reference's exact
 // arithmetic (exact_sphere_test_f32), in index order.  Spheres the bound would make useless
 // (|C'| > 64: the ground) get q' = -1e30 and are always re-tested.  Result: bit-identical.
-__device__ __forceinline__ void hit_world_screened(const RenderParams<float>& p, const float* lds_exact, const float* lds_screen,
-                                                   V3<float> O, V3<float> D, float a, float& closest, int& hit) {
-    float ox = O.x - p.ctr_x, oy = O.y - p.ctr_y, oz = O.z - p.ctr_z;
-    const float rs = __builtin_amdgcn_rsqf(a);    // screen only: |d^| = 1 +- 2^-22
-    float dx = D.x * rs, dy = D.y * rs, dz = D.z * rs;
+__device__ __forceinline__ void exact_sphere_test_f64(const double* g, int s, V3<double> O, V3<double> D, double a, double& closest, int& hit) {
+    const double cx = g[4 * s], cy = g[4 * s + 1], cz = g[4 * s + 2], r2 = g[4 * s + 3];
+    const double ocx = cx - O.x, ocy = cy - O.y, ocz = cz - O.z;                                   // :42
+    const double h = __builtin_fma(D.z, ocz, __builtin_fma(D.y, ocy, D.x * ocx));                  // :44
+    const double c = __builtin_fma(ocz, ocz, __builtin_fma(ocy, ocy, ocx * ocx)) - r2;             // :45
+    const double disc = __builtin_fma(h, h, -(a * c));                                             // :47
+    if (disc >= 0.0) finish_sphere_test<double>(s, h, disc, a, closest, hit);                      // :48-57
+}
+
+__device__ __forceinline__ void exact_sphere_test(const float* g, int s, V3<float> O, V3<float> D, float a, float& closest, int& hit) {
+    exact_sphere_test_f32(g, s, O, D, a, closest, hit);
+}
+__device__ __forceinline__ void exact_sphere_test(const double* g, int s, V3<double> O, V3<double> D, double a, double& closest, int& hit) {
+    exact_sphere_test_f64(g, s, O, D, a, closest, hit);
+}
+
+// The screen itself always runs in packed fp32, for both precisions: it only has to be
+// conservative.  fp64 rays are rounded to fp32 first (one more 2^-24 relative perturbation of O'
+// and d, of the kind the margin already covers for the recentring), and the fp64 reference
+// discriminant carries ~2^-53 instead of 18 * 2^-24 of rounding, so the fp32 margins hold a
+// fortiori; candidates are re-tested with the exact fp64 arithmetic.  21 instead of 36 issue
+// cycles per sphere (v_pk_fma_f32 vs v_fma_f64, bin/valu_cost).
+template <class T>
+__device__ __forceinline__ void hit_world_screened(const RenderParams<T>& p, const T* lds_exact, const float* lds_screen,
+                                                   V3<T> O, V3<T> D, T a, T& closest, int& hit) {
+    float ox = (float)(O.x - p.ctr_x), oy = (float)(O.y - p.ctr_y), oz = (float)(O.z - p.ctr_z);
+    float dx = (float)D.x, dy = (float)D.y, dz = (float)D.z;
+    const float af = sizeof(T) == 4 ? (float)a : __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    const float rs = __builtin_amdgcn_rsqf(af);   // screen only: |d^| = 1 +- 2^-22
+    dx *= rs; dy *= rs; dz *= rs;
     float nk1 = -__builtin_fmaf(dz, oz, __builtin_fmaf(dy, oy, dx * ox));
     float k2 = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
-    k2 = k2 - 7.62939453125e-06f * __builtin_fmaf(p.omax2, fast_sqrt(k2), k2);   // - 2^-17 (2 Cmax |O'| + |O'|^2); p.omax2 holds 2 Cmax (1 + 2^-20): raw sqrt
+    k2 = k2 - 7.62939453125e-06f * __builtin_fmaf((float)p.omax2, fast_sqrt(k2), k2);   // - 2^-17 (2 Cmax |O'| + |O'|^2); p.omax2 holds 2 Cmax (1 + 2^-20): raw sqrt
     float mx = -2.0f * ox, my = -2.0f * oy, mz = -2.0f * oz;
     asm volatile("" : "+v"(nk1), "+v"(k2), "+v"(mx), "+v"(my), "+v"(mz), "+v"(dx), "+v"(dy), "+v"(dz));
     const v2f vnk1 = {nk1, nk1}, vk2 = {k2, k2}, vmx = {mx, mx}, vmy = {my, my}, vmz = {mz, mz};
@@ -457,50 +482,10 @@ __device__ __forceinline__ void hit_world_screened(const RenderParams<float>& p,
         }
         const float m = __builtin_fmaxf(__builtin_fmaxf(dsc[0].x, dsc[0].y), __builtin_fmaxf(dsc[1].x, dsc[1].y));
         if (!(m < 0.0f)) {                        // some sphere of the trip may pass hittable.h:48 (NaNs are kept)
-            if (!(dsc[0].x < 0.0f)) exact_sphere_test_f32(lds_exact, s + 0, O, D, a, closest, hit);
-            if (!(dsc[0].y < 0.0f)) exact_sphere_test_f32(lds_exact, s + 1, O, D, a, closest, hit);
-            if (!(dsc[1].x < 0.0f)) exact_sphere_test_f32(lds_exact, s + 2, O, D, a, closest, hit);
-            if (!(dsc[1].y < 0.0f)) exact_sphere_test_f32(lds_exact, s + 3, O, D, a, closest, hit);
-        }
-    }
-}
-
-// fp64 twin of the screen: scalar operations on the plain {cx',cy',cz',q'} table (8 instead of 12
-// per sphere).  It keeps the fp32 margins (2^-17): the raw v_rsq_f64 behind the unit direction is
-// only ~2^-26 accurate, which those margins cover a hundred times over, and the false-positive
-// rate (+3 % candidates) is what fp32 pays anyway.
-__device__ __forceinline__ void exact_sphere_test_f64(const double* g, int s, V3<double> O, V3<double> D, double a, double& closest, int& hit) {
-    const double cx = g[4 * s], cy = g[4 * s + 1], cz = g[4 * s + 2], r2 = g[4 * s + 3];
-    const double ocx = cx - O.x, ocy = cy - O.y, ocz = cz - O.z;                                   // :42
-    const double h = __builtin_fma(D.z, ocz, __builtin_fma(D.y, ocy, D.x * ocx));                  // :44
-    const double c = __builtin_fma(ocz, ocz, __builtin_fma(ocy, ocy, ocx * ocx)) - r2;             // :45
-    const double disc = __builtin_fma(h, h, -(a * c));                                             // :47
-    if (disc >= 0.0) finish_sphere_test<double>(s, h, disc, a, closest, hit);                      // :48-57
-}
-
-__device__ __forceinline__ void hit_world_screened(const RenderParams<double>& p, const double* lds_exact, const double* lds_screen,
-                                                   V3<double> O, V3<double> D, double a, double& closest, int& hit) {
-    const double ox = O.x - p.ctr_x, oy = O.y - p.ctr_y, oz = O.z - p.ctr_z;
-    const double rs = __builtin_amdgcn_rsq(a);
-    const double dx = D.x * rs, dy = D.y * rs, dz = D.z * rs;
-    const double nk1 = -__builtin_fma(dz, oz, __builtin_fma(dy, oy, dx * ox));
-    double k2 = __builtin_fma(oz, oz, __builtin_fma(oy, oy, ox * ox));
-    k2 = k2 - 7.62939453125e-06 * __builtin_fma(p.omax2, fast_sqrt(k2), k2);
-    const double mx = -2.0 * ox, my = -2.0 * oy, mz = -2.0 * oz;
-    for (int s = 0; s < p.n_padded; s += 4) {
-        double dsc[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double cx = lds_screen[4 * (s + k)], cy = lds_screen[4 * (s + k) + 1], cz = lds_screen[4 * (s + k) + 2], qq = lds_screen[4 * (s + k) + 3];
-            const double hh = __builtin_fma(dz, cz, __builtin_fma(dy, cy, __builtin_fma(dx, cx, nk1)));
-            const double cc = __builtin_fma(mz, cz, __builtin_fma(my, cy, __builtin_fma(mx, cx, qq + k2)));
-            dsc[k] = __builtin_fma(hh, hh, -cc);
-        }
-        const double m = __builtin_fmax(__builtin_fmax(dsc[0], dsc[1]), __builtin_fmax(dsc[2], dsc[3]));
-        if (!(m < 0.0)) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (!(dsc[k] < 0.0)) exact_sphere_test_f64(lds_exact, s + k, O, D, a, closest, hit);
+            if (!(dsc[0].x < 0.0f)) exact_sphere_test(lds_exact, s + 0, O, D, a, closest, hit);
+            if (!(dsc[0].y < 0.0f)) exact_sphere_test(lds_exact, s + 1, O, D, a, closest, hit);
+            if (!(dsc[1].x < 0.0f)) exact_sphere_test(lds_exact, s + 2, O, D, a, closest, hit);
+            if (!(dsc[1].y < 0.0f)) exact_sphere_test(lds_exact, s + 3, O, D, a, closest, hit);
         }
     }
 }
@@ -514,7 +499,7 @@ __device__ __forceinline__ void hit_world<double, RTIOW_SCENE_LDS>(const RenderP
                                                                    double a, double& closest, int& hit) {
     if (p.use_screen) {
         extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-        hit_world_screened(p, lds_geom, reinterpret_cast<const double*>(smem_raw + p.screen_offset), O, D, a, closest, hit);
+        hit_world_screened<double>(p, lds_geom, reinterpret_cast<const float*>(smem_raw + p.screen_offset), O, D, a, closest, hit);
     } else {
         hit_world_direct<double, RTIOW_SCENE_LDS>(p, lds_geom, O, D, a, closest, hit);
     }
@@ -524,7 +509,7 @@ __device__ __forceinline__ void hit_world<float, RTIOW_SCENE_LDS>(const RenderPa
                                                                   float a, float& closest, int& hit) {
     if (p.use_screen) {
         extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-        hit_world_screened(p, lds_geom, reinterpret_cast<const float*>(smem_raw + p.screen_offset), O, D, a, closest, hit);
+        hit_world_screened<float>(p, lds_geom, reinterpret_cast<const float*>(smem_raw + p.screen_offset), O, D, a, closest, hit);
     } else {
         hit_world_direct<float, RTIOW_SCENE_LDS>(p, lds_geom, O, D, a, closest, hit);
     }
@@ -761,7 +746,7 @@ __device__ __forceinline__ T* stage_scene(const RenderParams<T>& p) {
         if (SRC == RTIOW_SCENE_LDS) {
             for (int k = threadIdx.x; k < p.n_padded * 4; k += blockDim.x) lds_geom[k] = p.geom_a[k];
             if (p.use_screen) {
-                T* lds_screen = reinterpret_cast<T*>(smem_raw + p.screen_offset);
+                float* lds_screen = reinterpret_cast<float*>(smem_raw + p.screen_offset);   // fp32 for both precisions
                 for (int k = threadIdx.x; k < p.n_padded * 4; k += blockDim.x) lds_screen[k] = p.geom_s[k];
             }
         }
@@ -1271,10 +1256,11 @@ int upload_scene(rtiow_handle_s* h, int n, const T* cr, const T* af, const T* ri
 
 // Builds the screening table of hit_world_screened for the current scene: centres recentred on
 // the scene's centroid (ground-like spheres excluded), q' = |C'|^2 - r^2 - 2^-17 (|C'|^2 + r^2)
-// rounded DOWN; fp32 pair-interleaved like geom_a, fp64 plain.  2 Cmax goes to the kernel for
-// the per-ray share of the margin.
+// rounded DOWN; always fp32 and pair-interleaved like the fp32 geom_a (the fp64 kernel screens in
+// fp32 too).  2 Cmax goes to the kernel for the per-ray share of the margin.
 template <class T>
 int build_screen_table(rtiow_handle_s* h) {
+    typedef float S;                                        // the screen runs in fp32 for both precisions
     const int m = h->n, mp = h->n_padded;
     const std::vector<double>& cr = h->host_cr;
     double ctr[3] = {0, 0, 0};
@@ -1283,41 +1269,41 @@ int build_screen_table(rtiow_handle_s* h) {
         if (cr[4 * i + 3] < 100.0) { for (int k = 0; k < 3; ++k) ctr[k] += cr[4 * i + k]; ++cnt; }
     if (cnt) for (int k = 0; k < 3; ++k) ctr[k] /= cnt;
     for (int k = 0; k < 3; ++k) h->ctr[k] = (double)(T)ctr[k];
-    std::vector<T> lin((size_t)mp * 4);
+    std::vector<S> lin((size_t)mp * 4);
     double cmax = 0;                                        // max |C'| over the spheres that are screened
     for (int i = 0; i < mp; ++i) {
-        if (i >= m) { lin[4 * i] = lin[4 * i + 1] = lin[4 * i + 2] = 0; lin[4 * i + 3] = (T)1e12; continue; }   // padding: c~ huge => never a candidate
+        if (i >= m) { lin[4 * i] = lin[4 * i + 1] = lin[4 * i + 2] = 0; lin[4 * i + 3] = (S)1e12; continue; }   // padding: c~ huge => never a candidate
         double c2 = 0;
         for (int k = 0; k < 3; ++k) {
-            const T cp = (T)(cr[4 * i + k] - h->ctr[k]);    // what the kernel will use as C'
+            const S cp = (S)(cr[4 * i + k] - h->ctr[k]);    // what the kernel will use as C'
             lin[4 * i + k] = cp;
             c2 += (double)cp * (double)cp;
         }
-        if (std::sqrt(c2) > 64.0) { lin[4 * i + 3] = (T)-1e30; continue; }         // e.g. the ground: always re-tested exactly
+        if (std::sqrt(c2) > 64.0) { lin[4 * i + 3] = (S)-1e30; continue; }         // e.g. the ground: always re-tested exactly
         cmax = std::max(cmax, std::sqrt(c2));
         const double r = cr[4 * i + 3], r2 = r * r;
         const double kappa = std::ldexp(1.0, -17) * (c2 + r2);                     // the sphere's share of the margin
-        T q = (T)(c2 - r2 - kappa);
-        if ((double)q > c2 - r2 - kappa) q = std::nextafter(q, (T)-INFINITY);
+        S q = (S)(c2 - r2 - kappa);
+        if ((double)q > c2 - r2 - kappa) q = std::nextafter(q, (S)-INFINITY);
         lin[4 * i + 3] = q;
     }
     h->omax2 = 2.0 * cmax * 1.000001;                       // per-ray share uses 2 Cmax |O'| + |O'|^2; the slack covers the raw sqrt (<= 2^-22 relative) in the kernel
-    if (sizeof(T) == 4) {
-        std::vector<T> pi(lin.size());
+    {
+        std::vector<S> pi(lin.size());
         for (int q = 0; q < mp / 2; ++q)
             for (int k = 0; k < 4; ++k) { pi[8 * q + 2 * k] = lin[8 * q + k]; pi[8 * q + 2 * k + 1] = lin[8 * q + 4 + k]; }
         lin.swap(pi);
     }
     if (h->geom_s) { HIP_TRY(h, hipFree(h->geom_s)); h->geom_s = nullptr; }
-    HIP_TRY(h, hipMalloc(&h->geom_s, lin.size() * sizeof(T)));
-    HIP_TRY(h, hipMemcpy(h->geom_s, lin.data(), lin.size() * sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMalloc(&h->geom_s, lin.size() * sizeof(S)));
+    HIP_TRY(h, hipMemcpy(h->geom_s, lin.data(), lin.size() * sizeof(S), hipMemcpyHostToDevice));
     h->screen_dirty = false;
     return 0;
 }
 
 template <class T>
 void fill_screen_params(RenderParams<T>& p, const rtiow_handle_s* h) {
-    p.geom_s = (const T*)h->geom_s;
+    p.geom_s = (const float*)h->geom_s;
     p.use_screen = (h->scene_source == RTIOW_SCENE_LDS && h->geom_s) ? 1 : 0;
     p.ctr_x = (T)h->ctr[0]; p.ctr_y = (T)h->ctr[1]; p.ctr_z = (T)h->ctr[2]; p.omax2 = (T)h->omax2;
 }
@@ -1355,7 +1341,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     fill_screen_params<T>(p, h);
     size_t lds = lds_source ? sizeof(T) * 4 * (size_t)h->n_padded : 0;
     p.screen_offset = (int)lds;
-    if (p.use_screen) lds += sizeof(T) * 4 * (size_t)h->n_padded;
+    if (p.use_screen) lds += sizeof(float) * 4 * (size_t)h->n_padded;
     p.timeline = seg_counter ? h->timeline : nullptr;
     // shade records ride along in LDS while a workgroup's share stays within 1/5 of the CU's LDS
     const size_t coop_bytes = persistent ? (size_t)((threads + 63) / 64) * 64 * sizeof(CoopSlot<T>) : 0;

@@ -275,6 +275,11 @@ def test_screen_equals_exact_fp64(rt, oracle):
     assert _same_bits(a, b)
     want, _ = _oracle(oracle, rt, 64, 3, W, H, S, B, rows=(200, 202))
     assert _same_bits(a[200:202], want)
+    # the fp64 kernel screens in packed fp32 (rays rounded to fp32 for the screen only): also on
+    # the 488-sphere scene, whose centres lie up to 16 units from the recentring point
+    a1 = _render(rt, 64, 1, 320, 192, 10, 25, threads=0)
+    b1 = _render(rt, 64, 1, 320, 192, 10, 25, threads=0, source=rt.SCENE_LDS_EXACT, sched=rt.SCHED_STATIC)
+    assert _same_bits(a1, b1)
 
 
 def test_baseline_config3_1280x720(rt, oracle):
