@@ -10,9 +10,12 @@ row strips, then one RCCL gather of the strips to rank 0 -- the gather is inside
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline      dominant kernel (render) against the fp32 VALU peak: algorithmic flops per
-                launch = segments*(23*N+120) + rays*60 (segments counted on the
-                device by rtiow_count_segments) / mean HIP-event kernel time of the timed steps
+  roofline      dominant kernel = the main launch of the render (render_persistent_kernel; the
+                sorted schedule's prepass of 4 of the 100 samples is a separate, named launch)
+                against the VALU peak: algorithmic flops of that launch = segments*(23*N+120) +
+                rays*60 (segments counted per launch on the device by
+                rtiow_count_segments) / its mean HIP-event time over the timed steps.  The same
+                figures for the whole step (all launches) are under "step".
   cpu_baseline  the reference's serial tracer (oracle/_ref, built from the reference's own
                 sources) or, if absent, the oracle's serial port, timed on this host (1 thread)
                 on a bounded sample of the same workload
@@ -85,7 +88,8 @@ def pmc_traffic(args):
     if not os.path.exists(path):
         return None
     key = "s%d_%dx%d_%dspp_%db_f%d" % (args.scene_id, args.width, args.height, args.samples, args.bounces, args.precision)
-    return json.load(open(path)).get(key, {}).get("hbm_bytes_per_launch")
+    e = json.load(open(path)).get(key, {})
+    return e.get("hbm_bytes_main_launch", e.get("hbm_bytes_per_launch"))
 
 
 def main():
@@ -135,8 +139,12 @@ def main():
     segments = r.count_segments(args.threads)          # untimed; also a first warm launch
     nspheres = r.stats()["num_spheres"]
 
+    main_ms = []
+
     def step(timed):
         ms = r.render(args.threads, sync=timed)        # HIP events on the launch stream
+        if timed:
+            main_ms.append(r.stats()["main_ms"])        # the main launch alone (events around it)
         if world > 1:
             gather.gather()
         return ms
@@ -167,14 +175,23 @@ def main():
         rays = float(W) * H * S
         ms_per_step = elapsed / args.steps * 1e3
         value = rays / (ms_per_step * 1e-3) / 1e6
-        # roofline of the dominant kernel (rank 0's launch; for N>1 this rank's shard)
-        my_rays = float(r.stats()["primary_rays"])
+        # roofline of the dominant kernel (rank 0's launches; for N>1 this rank's shard)
+        st = r.stats()
+        my_rays = float(st["primary_rays"])
         my_segments = float(segments)
-        flops = my_segments * (23.0 * nspheres + 120.0) + my_rays * 60.0
+        per_seg = 23.0 * nspheres + 120.0
+        flops_step = my_segments * per_seg + my_rays * 60.0
         kms = float(np.mean(kernel_ms))
         peak = VALU_FP32_PEAK_TFLOPS if prec == 32 else VALU_FP64_PEAK_TFLOPS
-        achieved = flops / (kms * 1e-3) / 1e12
-        fb_bytes = my_rays / S * 3 * (4 if prec == 32 else 8) + my_rays / S * 24
+        rays_main = my_rays * (S - st["prepass_samples"]) / S
+        flops = float(st["segments_main"]) * per_seg + rays_main * 60.0       # the main launch alone
+        mms = float(np.mean(main_ms))
+        achieved = flops / (mms * 1e-3) / 1e12
+        # algorithmic HBM bytes of the main launch, per pixel: the framebuffer write (3 T) + its starting state:
+        # the 48/64-byte hand-over record and a 4-byte order entry (sorted schedule) or the 24-byte RNG state
+        my_pixels = my_rays / S
+        state_bytes = ((48 if prec == 32 else 64) + 4) if st["phases"] == 2 else 24
+        fb_bytes = my_pixels * (3 * (4 if prec == 32 else 8) + state_bytes)
         line = {
             "metric": "Mrays/s (= W x H x samples / render time)",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -190,9 +207,16 @@ def main():
             "segments_per_ray": round(segments_total / rays, 4),
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args),
-                         "algorithmic_flops_per_launch": flops, "algorithmic_hbm_bytes_per_launch": fb_bytes,
-                         "hbm_achieved_GBps": round(fb_bytes / (kms * 1e-3) / 1e9, 3), "hbm_peak_GBps": HBM_PEAK_GBS,
-                         "kernel": "%s<%s>" % ("render_kernel" if args.schedule == "static" else "render_persistent_kernel", "float" if prec == 32 else "double")},
+                         "kernel": "%s<%s>" % ("render_kernel" if args.schedule == "static" else "render_persistent_kernel", "float" if prec == 32 else "double"),
+                         "launch_ms_mean": round(mms, 4), "launch_ms_min": round(float(np.min(main_ms)), 4),
+                         "algorithmic_flops_per_launch": flops, "segments_in_launch": int(st["segments_main"]),
+                         "samples_in_launch": int(S - st["prepass_samples"]),
+                         "algorithmic_hbm_bytes_per_launch": fb_bytes,
+                         "hbm_achieved_GBps": round(fb_bytes / (mms * 1e-3) / 1e9, 3), "hbm_peak_GBps": HBM_PEAK_GBS},
+            "step": {"launches": "prepass (%d spp) + cost sort + main" % st["prepass_samples"] if st["phases"] == 2 else "main",
+                     "kernel_ms_mean": round(kms, 4), "prepass_ms": round(float(st["prepass_ms"]), 4),
+                     "algorithmic_flops": flops_step, "achieved_TFLOPs": round(flops_step / (kms * 1e-3) / 1e12, 3),
+                     "frac_of_peak": round(flops_step / (kms * 1e-3) / 1e12 / peak, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)

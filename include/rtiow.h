@@ -91,6 +91,12 @@ typedef struct {
     int32_t  schedule;           /* RTIOW_SCHED_*                                          */
     int32_t  grid_blocks;        /* workgroups launched by the last render                 */
     int32_t  phases;             /* 2 when RTIOW_SCHED_SORTED split the render, else 1     */
+    int32_t  prepass_samples;    /* samples per pixel rendered by the prepass launch (0: none) */
+    double   prepass_ms;         /* HIP-event time of the prepass launch of the last timed render */
+    double   main_ms;            /* HIP-event time of the main launch (render_persistent_kernel /
+                                  * render_kernel): the dominant kernel of the roofline      */
+    uint64_t segments_prepass;   /* last rtiow_count_segments: hit_world calls per launch   */
+    uint64_t segments_main;
 } rtiow_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------

@@ -60,7 +60,9 @@ class Stats(ctypes.Structure):
                 ("num_spheres", ctypes.c_int32), ("block_x", ctypes.c_int32), ("block_y", ctypes.c_int32),
                 ("vgprs", ctypes.c_int32), ("sgprs", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
                 ("scene_source", ctypes.c_int32),
-                ("schedule", ctypes.c_int32), ("grid_blocks", ctypes.c_int32), ("phases", ctypes.c_int32)]
+                ("schedule", ctypes.c_int32), ("grid_blocks", ctypes.c_int32), ("phases", ctypes.c_int32),
+                ("prepass_samples", ctypes.c_int32), ("prepass_ms", ctypes.c_double), ("main_ms", ctypes.c_double),
+                ("segments_prepass", ctypes.c_uint64), ("segments_main", ctypes.c_uint64)]
 
 
 # Every symbol include/rtiow.h declares (tests check that the built library exports them all).

@@ -169,9 +169,12 @@ template <class T> struct RenderParams {
     // per-pixel state carried between the phases, and the cost-sorted hand-out order.
     int s_begin, s_end;               // samples [s_begin, s_end) of every pixel
     const uint32_t* __restrict__ rng_in;   // [6][npix] SoA state at sample s_begin
-    uint32_t* __restrict__ rng_out;   // phase A: state after sample s_end-1 (nullptr: final phase, pixel is stored)
-    const T* __restrict__ acc_in;     // [3][npix] colour sum of samples [0,s_begin) (nullptr: zero)
-    T* __restrict__ acc_out;          // phase A only
+    // SCHED_SORTED hand-over between the prepass and the main launch: ONE record per pixel
+    // (MidState<T>: RNG state after sample s_end-1 + colour sum), so that the main launch, which
+    // visits the pixels in cost order, fetches one or two cache lines per pixel instead of nine
+    // (SoA cost 630 MB of fetches per frame for 83 MB of state).
+    const unsigned char* __restrict__ mid_in;   // main launch: state at sample s_begin (nullptr: rng_in, zero sum)
+    unsigned char* __restrict__ mid_out;        // prepass: park the state (nullptr: final launch, the pixel is stored)
     uint32_t* __restrict__ cost_out;  // phase A only: segments the pixel ran in this phase
     const int* __restrict__ order;    // slot -> local pixel (or -1), nullptr: 8x8 tiles bottom-up
     int total_slots;
@@ -765,12 +768,40 @@ __device__ __forceinline__ int global_row(int jl, int strip_rows, int nranks, in
 
 // End of a pixel in one launch: the final phase writes the pixel
 // (camera.h:167-171); phase A of the sorted schedule parks the exact state instead.
+// Per-pixel hand-over record, read and written as 16-byte vectors: fp32 48 bytes, fp64 64 bytes.
+template <class T> struct MidState;
+template <> struct alignas(16) MidState<float>  { uint32_t v[5], d; float acc[3]; uint32_t pad[3]; };
+template <> struct alignas(16) MidState<double> { uint32_t v[5], d; uint32_t pad[2]; double acc[3]; uint32_t pad2[2]; };
+static_assert(sizeof(MidState<float>) == 48 && sizeof(MidState<double>) == 64, "hand-over record layout");
+
+template <class T>
+__device__ __forceinline__ void park_state(unsigned char* base, size_t lp, const PathState<T>& st) {
+    MidState<T> m;
+    m.v[0] = st.rs.v0; m.v[1] = st.rs.v1; m.v[2] = st.rs.v2; m.v[3] = st.rs.v3; m.v[4] = st.rs.v4; m.d = st.rs.d;
+    m.acc[0] = st.acc.x; m.acc[1] = st.acc.y; m.acc[2] = st.acc.z;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4* src = reinterpret_cast<const u4*>(&m);
+    u4* dst = reinterpret_cast<u4*>(base + lp * sizeof(MidState<T>));
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(MidState<T>) / 16); ++k) dst[k] = src[k];
+}
+template <class T>
+__device__ __forceinline__ void unpark_state(const unsigned char* base, size_t lp, PathState<T>& st) {
+    MidState<T> m;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4* src = reinterpret_cast<const u4*>(base + lp * sizeof(MidState<T>));
+    u4* dst = reinterpret_cast<u4*>(&m);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(MidState<T>) / 16); ++k) dst[k] = src[k];
+    st.rs.v0 = m.v[0]; st.rs.v1 = m.v[1]; st.rs.v2 = m.v[2]; st.rs.v3 = m.v[3]; st.rs.v4 = m.v[4]; st.rs.d = m.d;
+    st.acc = {m.acc[0], m.acc[1], m.acc[2]};
+}
+
 template <class T>
 __device__ __forceinline__ void finish_pixel(const RenderParams<T>& p, size_t lp, size_t npix, const PathState<T>& st, unsigned int cost) {
-    if (p.rng_out) {
-        p.rng_out[0 * npix + lp] = st.rs.v0; p.rng_out[1 * npix + lp] = st.rs.v1; p.rng_out[2 * npix + lp] = st.rs.v2;
-        p.rng_out[3 * npix + lp] = st.rs.v3; p.rng_out[4 * npix + lp] = st.rs.v4; p.rng_out[5 * npix + lp] = st.rs.d;
-        p.acc_out[0 * npix + lp] = st.acc.x; p.acc_out[1 * npix + lp] = st.acc.y; p.acc_out[2 * npix + lp] = st.acc.z;
+    (void)npix;
+    if (p.mid_out) {
+        park_state<T>(p.mid_out, lp, st);
         p.cost_out[lp] = cost;
     } else {
         store_pixel(p, lp, st.acc);
@@ -836,8 +867,7 @@ render_kernel(const RenderParams<T> p) {
 constexpr int POOL = 64;
 
 template <class T, int SRC, bool COUNT>
-__global__ void __launch_bounds__(1024)
-render_persistent_kernel(const RenderParams<T> p) {
+__device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
     const T* lds_geom = stage_scene<T, SRC>(p);
     // per-wave scratch for hit_world_coop, behind the staged tables
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -912,10 +942,12 @@ render_persistent_kernel(const RenderParams<T> p) {
                         want = false;
                         j = global_row(jl, p.strip_rows, p.nranks, p.rank);
                         lp = (size_t)jl * p.W + i;
-                        st.rs.v0 = p.rng_in[0 * npix + lp]; st.rs.v1 = p.rng_in[1 * npix + lp]; st.rs.v2 = p.rng_in[2 * npix + lp];
-                        st.rs.v3 = p.rng_in[3 * npix + lp]; st.rs.v4 = p.rng_in[4 * npix + lp]; st.rs.d = p.rng_in[5 * npix + lp];
-                        if (p.acc_in) st.acc = {p.acc_in[0 * npix + lp], p.acc_in[1 * npix + lp], p.acc_in[2 * npix + lp]};
-                        else st.acc = {0, 0, 0};
+                        if (p.mid_in) unpark_state<T>(p.mid_in, lp, st);
+                        else {
+                            st.rs.v0 = p.rng_in[0 * npix + lp]; st.rs.v1 = p.rng_in[1 * npix + lp]; st.rs.v2 = p.rng_in[2 * npix + lp];
+                            st.rs.v3 = p.rng_in[3 * npix + lp]; st.rs.v4 = p.rng_in[4 * npix + lp]; st.rs.d = p.rng_in[5 * npix + lp];
+                            st.acc = {0, 0, 0};
+                        }
                         st.sample = p.s_begin; st.depth = 0;
                         cost = 0;
                         if (COUNT) ++n_pixels;
@@ -977,6 +1009,14 @@ render_persistent_kernel(const RenderParams<T> p) {
         }
     }
 }
+
+// The same body under two kernel names, so that profiles tell the launches of RTIOW_SCHED_SORTED
+// apart: the prepass (samples [0, SA) in tile order, ~1.4 ms of the headline frame) and the main
+// launch (everything else; also the only launch of RTIOW_SCHED_PERSISTENT).
+template <class T, int SRC, bool COUNT>
+__global__ void __launch_bounds__(1024) render_persistent_kernel(const RenderParams<T> p) { persistent_body<T, SRC, COUNT>(p); }
+template <class T, int SRC, bool COUNT>
+__global__ void __launch_bounds__(1024) render_prepass_kernel(const RenderParams<T> p) { persistent_body<T, SRC, COUNT>(p); }
 
 // Elementwise arithmetic probes (tests compare these with the host bit for bit).
 template <class T>
@@ -1112,7 +1152,8 @@ struct rtiow_handle_s {
     int precision = 32;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_a = nullptr, ev_b = nullptr;   // ev_a: prepass done, ev_b: main launch starts
+    bool time_phases = false;
     std::string err;
 
     // scene
@@ -1141,8 +1182,7 @@ struct rtiow_handle_s {
     // knobs / stats
     int scene_source = RTIOW_SCENE_LDS;
     int schedule = RTIOW_SCHED_SORTED;
-    uint32_t* rng_mid = nullptr; size_t rng_mid_bytes = 0;      // SCHED_SORTED: state parked between the phases
-    void* acc_mid = nullptr; size_t acc_mid_bytes = 0;
+    unsigned char* mid = nullptr; size_t mid_bytes = 0;          // SCHED_SORTED: MidState records parked between the launches
     uint32_t* cost = nullptr; size_t cost_bytes = 0;
     int* order = nullptr; size_t order_bytes = 0;
     unsigned* sort_scratch = nullptr; size_t sort_scratch_bytes = 0;
@@ -1315,6 +1355,11 @@ RenderFn<T> pick_sched(bool persistent) {
     return persistent ? render_persistent_kernel<T, SRC, COUNT> : render_kernel<T, SRC, COUNT>;
 }
 template <class T>
+RenderFn<T> pick_prepass_kernel(bool lds, bool count) {
+    if (lds) return count ? (RenderFn<T>)render_prepass_kernel<T, RTIOW_SCENE_LDS, true> : (RenderFn<T>)render_prepass_kernel<T, RTIOW_SCENE_LDS, false>;
+    return count ? (RenderFn<T>)render_prepass_kernel<T, RTIOW_SCENE_SCALAR, true> : (RenderFn<T>)render_prepass_kernel<T, RTIOW_SCENE_SCALAR, false>;
+}
+template <class T>
 RenderFn<T> pick_kernel(bool persistent, bool lds, bool count) {
     if (lds) return count ? pick_sched<T, RTIOW_SCENE_LDS, true>(persistent) : pick_sched<T, RTIOW_SCENE_LDS, false>(persistent);
     return count ? pick_sched<T, RTIOW_SCENE_SCALAR, true>(persistent) : pick_sched<T, RTIOW_SCENE_SCALAR, false>(persistent);
@@ -1333,7 +1378,8 @@ int ensure_buffer(rtiow_handle_s* h, P** ptr, size_t* have, size_t need) {
 template <class T, class CAM>
 int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_tiles, unsigned long long* seg_counter = nullptr) {
     RenderParams<T> p = make_params<T>(h, cam);
-    p.bx = bx; p.by = by; p.wave_tiles = wave_tiles; p.seg_counter = seg_counter;
+    p.bx = bx; p.by = by; p.wave_tiles = wave_tiles;
+    p.seg_counter = seg_counter ? seg_counter + 1 : nullptr;     // [0] prepass launch, [1] main (or only) launch
     const bool persistent = h->schedule != RTIOW_SCHED_STATIC;
     const int threads = bx * by;
     const bool lds_source = h->scene_source != RTIOW_SCENE_SCALAR;
@@ -1382,14 +1428,13 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         // phase A length: enough samples to rank the pixels, a small share of the frame
         const int SA = S >= 64 ? 4 : (S >= 24 ? 2 : 0);   // 2..6 measured equal on the headline config
         p.work_counter = h->work_counter;
-        p.s_begin = 0; p.s_end = S; p.rng_in = h->rng; p.rng_out = nullptr; p.acc_in = nullptr; p.acc_out = nullptr;
+        p.s_begin = 0; p.s_end = S; p.rng_in = h->rng; p.mid_in = nullptr; p.mid_out = nullptr;
         p.cost_out = nullptr; p.order = nullptr; p.total_slots = (int)tile_slots; p.first_pools = 0;
         if (h->schedule == RTIOW_SCHED_SORTED && SA > 0 && npix >= 4096) {
             phases = 2;
             const int total_pools = (npix + POOL - 1) / POOL;
             int rc;
-            if ((rc = ensure_buffer(h, &h->rng_mid, &h->rng_mid_bytes, (size_t)npix * 6 * sizeof(uint32_t)))) return rc;
-            if ((rc = ensure_buffer(h, (unsigned char**)&h->acc_mid, &h->acc_mid_bytes, (size_t)npix * 3 * sizeof(T)))) return rc;
+            if ((rc = ensure_buffer(h, &h->mid, &h->mid_bytes, (size_t)npix * sizeof(MidState<T>)))) return rc;
             if ((rc = ensure_buffer(h, &h->cost, &h->cost_bytes, (size_t)npix * sizeof(uint32_t)))) return rc;
             if ((rc = ensure_buffer(h, &h->order, &h->order_bytes, (size_t)total_pools * POOL * sizeof(int)))) return rc;
             if ((rc = ensure_buffer(h, &h->sort_scratch, &h->sort_scratch_bytes, (size_t)3 * COST_BINS * sizeof(unsigned)))) return rc;
@@ -1397,8 +1442,13 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             // static kernel keeps only ~40 % of its lanes busy over 4 samples: 2.6 ms vs 1.4 ms
             // measured); RNG state, colour sum and segment count are parked per pixel.
             RenderParams<T> pa = p;
-            pa.s_end = SA; pa.rng_out = h->rng_mid; pa.acc_out = (T*)h->acc_mid; pa.cost_out = h->cost;
-            hipLaunchKernelGGL(k, grid, block, lds, h->stream, pa);
+            pa.s_end = SA; pa.mid_out = h->mid; pa.cost_out = h->cost;
+            pa.seg_counter = seg_counter;
+            RenderFn<T> kp = pick_prepass_kernel<T>(lds_source, seg_counter != nullptr);
+            if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kp, grid, block, lds, h->stream, pa);
+            if (h->time_phases) HIP_TRY(h, hipEventRecord(h->ev_a, h->stream));
+            h->stats.prepass_samples = SA;
             HIP_TRY(h, hipGetLastError());
             // ---- rank the pixels by measured cost, heavy first, dealt into balanced pools.
             // Blocks of the order are one "age class" of resident waves wide (see first_pools).
@@ -1417,7 +1467,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
                                pools_per_block, total_pools);
             HIP_TRY(h, hipGetLastError());
             // ---- phase B: samples [SA, S) in that order
-            p.s_begin = SA; p.rng_in = h->rng_mid; p.acc_in = (const T*)h->acc_mid; p.order = h->order;
+            p.s_begin = SA; p.mid_in = h->mid; p.order = h->order;
             p.total_slots = total_pools * POOL;
             p.work_counter = h->work_counter + 1;
             p.first_pools = 1;
@@ -1426,9 +1476,10 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         }
     } else {
         grid = dim3((p.W + bx - 1) / bx, (h->local_rows + by - 1) / by);
-        p.s_begin = 0; p.s_end = p.S; p.rng_in = h->rng; p.rng_out = nullptr; p.acc_in = nullptr; p.acc_out = nullptr;
+        p.s_begin = 0; p.s_end = p.S; p.rng_in = h->rng; p.mid_in = nullptr; p.mid_out = nullptr;
         p.cost_out = nullptr; p.order = nullptr; p.total_slots = 0; p.first_pools = 0; p.work_counter = nullptr;
     }
+    if (h->time_phases && phases == 2) HIP_TRY(h, hipEventRecord(h->ev_b, h->stream));
     hipLaunchKernelGGL(k, grid, block, lds, h->stream, p);
     HIP_TRY(h, hipGetLastError());
     if (seg_counter) h->last_count_blocks = (int)(grid.x * grid.y);
@@ -1441,6 +1492,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         h->stats.schedule = h->schedule;
         h->stats.grid_blocks = (int)(grid.x * grid.y);
         h->stats.phases = phases;
+        if (phases == 1) h->stats.prepass_samples = 0;
     }
     return 0;
 }
@@ -1478,7 +1530,8 @@ int rtiow_create(int device, int precision, rtiow_handle* out) {
     h->device = device; h->precision = precision;
     if ((e = hipSetDevice(device)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess) {
+        (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess ||
+        (e = hipEventCreate(&h->ev_a)) != hipSuccess || (e = hipEventCreate(&h->ev_b)) != hipSuccess) {
         delete h;
         return (int)e;
     }
@@ -1493,11 +1546,13 @@ int rtiow_destroy(rtiow_handle h) {
     if (!h) return RTIOW_E_BADARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->geom_a, h->shade_tbl, h->geom_s, h->rng, h->jump, h->work_counter, h->rng_mid, h->acc_mid,
+    void* bufs[] = {h->geom_a, h->shade_tbl, h->geom_s, h->rng, h->jump, h->work_counter, h->mid,
                     h->cost, h->order, h->sort_scratch, h->fb_external ? nullptr : h->fb};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_a) (void)hipEventDestroy(h->ev_a);
+    if (h->ev_b) (void)hipEventDestroy(h->ev_b);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -1611,8 +1666,10 @@ int rtiow_render(rtiow_handle h, int threads_per_block_row, float* kernel_ms) {
     int bx, by, wave_tiles;
     block_shape(T, bx, by, wave_tiles);
     if (kernel_ms) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));                     // main.cu:334
+    h->time_phases = kernel_ms != nullptr;
     if (h->precision == 32) rc = launch_render<float>(h, h->cam32, bx, by, wave_tiles);
     else rc = launch_render<double>(h, h->cam64, bx, by, wave_tiles);
+    h->time_phases = false;
     if (rc) return rc;
     const int S = h->precision == 32 ? h->cam32.samples_per_pixel : h->cam64.samples_per_pixel;
     h->stats.primary_rays = (uint64_t)h->local_rows * img_w(h) * (uint64_t)S;
@@ -1623,6 +1680,13 @@ int rtiow_render(rtiow_handle h, int threads_per_block_row, float* kernel_ms) {
         HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
         *kernel_ms = ms;
         h->stats.render_ms = ms;
+        h->stats.prepass_ms = 0; h->stats.main_ms = ms;
+        if (h->stats.phases == 2) {
+            float a = 0, b = 0;
+            HIP_TRY(h, hipEventElapsedTime(&a, h->ev0, h->ev_a));
+            HIP_TRY(h, hipEventElapsedTime(&b, h->ev_b, h->ev1));
+            h->stats.prepass_ms = a; h->stats.main_ms = b;
+        }
     }
     return 0;
 }
@@ -1638,19 +1702,20 @@ int rtiow_count_segments(rtiow_handle h, int threads_per_block_row, uint64_t* se
     if (rc) return rc;
     *segments = 0;
     if (h->local_rows == 0) return 0;
-    unsigned long long* d = nullptr;
-    HIP_TRY(h, hipMalloc((void**)&d, sizeof *d));
-    HIP_TRY(h, hipMemsetAsync(d, 0, sizeof *d, h->stream));
+    unsigned long long* d = nullptr;                     // [0] prepass launch, [1] main (or only) launch
+    HIP_TRY(h, hipMalloc((void**)&d, 2 * sizeof *d));
+    HIP_TRY(h, hipMemsetAsync(d, 0, 2 * sizeof *d, h->stream));
     int bx, by, wave_tiles;
     block_shape(T, bx, by, wave_tiles);
     if (h->precision == 32) rc = launch_render<float>(h, h->cam32, bx, by, wave_tiles, d);
     else rc = launch_render<double>(h, h->cam64, bx, by, wave_tiles, d);
     if (rc) { (void)hipFree(d); return rc; }
-    unsigned long long host = 0;
-    HIP_TRY(h, hipMemcpyAsync(&host, d, sizeof host, hipMemcpyDeviceToHost, h->stream));
+    unsigned long long host[2] = {0, 0};
+    HIP_TRY(h, hipMemcpyAsync(host, d, sizeof host, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     (void)hipFree(d);
-    *segments = host;
+    *segments = host[0] + host[1];
+    h->stats.segments_prepass = host[0]; h->stats.segments_main = host[1];
     return 0;
 }
 

@@ -150,6 +150,28 @@ def test_block_shapes_and_scene_sources_give_the_same_image(rt, oracle):
         assert _same_bits(_render(rt, 64, 3, 50, 30, 2, 12, threads, rt.SCENE_SCALAR), want64)
 
 
+def test_per_launch_timing_and_segment_counts(rt):
+    """The sorted schedule's two launches are timed and counted separately (bench.py's roofline is
+    the main launch): event times nest inside the render time, segment counts add up."""
+    W, H, S, B = 256, 144, 64, 20
+    with rt.Renderer(0, 32) as r:
+        r.set_camera(rt.camera(32, W, H, S, B)); r.set_scene(rt.build_scene(3, 32)); r.init_rng(1227)
+        r.set_schedule(rt.SCHED_SORTED)
+        ms = r.render(0)
+        total = r.count_segments(0)
+        st = r.stats()
+        assert st["phases"] == 2 and st["prepass_samples"] == 4
+        assert 0 < st["prepass_ms"] and 0 < st["main_ms"] and st["prepass_ms"] + st["main_ms"] <= ms * 1.001
+        assert st["segments_prepass"] + st["segments_main"] == total
+        assert 0.02 < st["segments_prepass"] / total < 0.12            # 4 of 64 samples
+        r.set_schedule(rt.SCHED_PERSISTENT)
+        ms = r.render(0)
+        assert r.count_segments(0) == total
+        st = r.stats()
+        assert st["phases"] == 1 and st["prepass_samples"] == 0 and st["segments_prepass"] == 0 and st["segments_main"] == total
+        assert abs(st["main_ms"] - ms) < 1e-6 and st["prepass_ms"] == 0
+
+
 def test_segment_count_matches_oracle(rt, oracle):
     for prec, sid, W, H, S, B in [(32, 3, 96, 56, 5, 25), (32, 1, 64, 40, 3, 50), (64, 2, 40, 24, 4, 10), (32, 3, 128, 64, 30, 25)]:
         want, stats = _oracle(oracle, rt, prec, sid, W, H, S, B)
