@@ -1033,20 +1033,21 @@ __global__ void debug_ops_kernel(int op, size_t n, const T* a, const T* b, const
     }
 }
 
-// ---- SCHED_SORTED: counting sort of the pixels by the cost measured in phase A, heavy first,
+// ---- SCHED_SORTED: counting sort of the pixels by the cost measured in the prepass, heavy first,
 // dealt into balanced pools.  Sorted rank r -> slot: ranks are cut into blocks of
-// `pools_per_block` pools (the resident waves); inside a block consecutive ranks go to
-// consecutive pools, so every pool of a block gets the same mix of costs and the blocks run
-// from the heaviest pixels to the lightest.
+// `pools_per_block` pools (the resident waves of one dispatch-age class); inside a block groups of
+// `group` consecutive ranks go to consecutive pools, so every pool of a block gets the same mix of
+// costs and the blocks run from the heaviest pixels to the lightest.  Ranks inside a cost bin follow
+// the image (64 x 64 super-tiles, 8 x 8 tiles), so a group is a handful of neighbouring pixels.
 constexpr int COST_BINS = 1024;
+__device__ __forceinline__ int cost_bin(unsigned c) { return c < (unsigned)COST_BINS ? (int)c : COST_BINS - 1; }
 
 __global__ void __launch_bounds__(256) cost_hist_kernel(const uint32_t* __restrict__ cost, int npix, unsigned* __restrict__ hist) {
     __shared__ unsigned local[COST_BINS];
     for (int b = threadIdx.x; b < COST_BINS; b += blockDim.x) local[b] = 0;
     __syncthreads();
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < npix; k += gridDim.x * blockDim.x) {
-        const unsigned c = cost[k];
-        atomicAdd(&local[c < COST_BINS ? c : COST_BINS - 1], 1u);
+        atomicAdd(&local[cost_bin(cost[k])], 1u);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < COST_BINS; b += blockDim.x) if (local[b]) atomicAdd(&hist[b], local[b]);
@@ -1072,21 +1073,26 @@ __global__ void __launch_bounds__(COST_BINS) cost_scan_kernel(const unsigned* __
 // non-empty bin to reserve the block's range of ranks, then LDS atomics for the rank inside it
 // (2 M contended global atomics on ~20 hot bins took 17.8 ms; this takes microseconds).
 constexpr int SCATTER_PER_THREAD = 4;
-__global__ void __launch_bounds__(1024) cost_scatter_kernel(const uint32_t* __restrict__ cost, int npix, const unsigned* __restrict__ start,
-                                                            unsigned* __restrict__ fill, int* __restrict__ order, int pools_per_block, int total_pools) {
+__global__ void __launch_bounds__(1024) cost_scatter_kernel(const uint32_t* __restrict__ cost, int W, int rows, const unsigned* __restrict__ start,
+                                                            unsigned* __restrict__ fill, int* __restrict__ order, int pools_per_block, int total_pools, int group) {
     __shared__ unsigned local[COST_BINS];        // block histogram, then the running rank inside the reserved range
     __shared__ unsigned base[COST_BINS];
     for (int b = threadIdx.x; b < COST_BINS; b += blockDim.x) local[b] = 0;
     __syncthreads();
-    const int first = blockIdx.x * blockDim.x * SCATTER_PER_THREAD;
-    int bins[SCATTER_PER_THREAD];
+    // A block ranks one 64 x 64-pixel super-tile, each wave an 8 x 8 tile of it, so that pixels which
+    // are neighbours in the image and equal in cost get adjacent ranks (see `group` below).
+    const int st_x = (W + 63) >> 6;
+    const int sx = (int)blockIdx.x % st_x, sy = (int)blockIdx.x / st_x;
+    int bins[SCATTER_PER_THREAD], pix[SCATTER_PER_THREAD];
 #pragma unroll
     for (int u = 0; u < SCATTER_PER_THREAD; ++u) {
-        const int k = first + u * (int)blockDim.x + (int)threadIdx.x;
+        const int idx = u * (int)blockDim.x + (int)threadIdx.x, tile = idx >> 6, within = idx & 63;
+        const int px = sx * 64 + (tile & 7) * 8 + (within & 7), py = sy * 64 + (tile >> 3) * 8 + (within >> 3);
+        const int k = (px < W && py < rows) ? py * W + px : -1;
+        pix[u] = k;
         bins[u] = -1;
-        if (k < npix) {
-            const unsigned c = cost[k];
-            bins[u] = c < COST_BINS ? (int)c : COST_BINS - 1;
+        if (k >= 0) {
+            bins[u] = cost_bin(cost[k]);
             atomicAdd(&local[bins[u]], 1u);
         }
     }
@@ -1101,12 +1107,13 @@ __global__ void __launch_bounds__(1024) cost_scatter_kernel(const uint32_t* __re
 #pragma unroll
     for (int u = 0; u < SCATTER_PER_THREAD; ++u) {
         if (bins[u] < 0) continue;
-        const int k = first + u * (int)blockDim.x + (int)threadIdx.x;
+        const int k = pix[u];
         const int r = (int)(base[bins[u]] + atomicAdd(&local[bins[u]], 1u));   // sorted rank (order inside a bin is immaterial)
         const int blk = r / per_block, q = r - blk * per_block;
         const int pools_here = (blk + 1) * pools_per_block <= total_pools ? pools_per_block : total_pools - blk * pools_per_block;
-        const int pool = blk * pools_per_block + q % pools_here;
-        const int lane_slot = q / pools_here;
+        const int g = q / group, j = q - g * group;                 // groups of `group` consecutive ranks stay together
+        const int pool = blk * pools_per_block + g % pools_here;
+        const int lane_slot = (g / pools_here) * group + j;
         order[pool * POOL + lane_slot] = k;
     }
 }
@@ -1462,9 +1469,18 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             const int age_classes = (int)((blocks + h->num_cus - 1) / h->num_cus);
             int pools_per_block = (resident_waves + age_classes - 1) / age_classes;
             if (pools_per_block > total_pools) pools_per_block = total_pools;
-            const int scatter_blocks = (npix + 1024 * SCATTER_PER_THREAD - 1) / (1024 * SCATTER_PER_THREAD);
-            hipLaunchKernelGGL(cost_scatter_kernel, dim3(scatter_blocks), dim3(1024), 0, h->stream, h->cost, npix, start, fill, h->order,
-                               pools_per_block, total_pools);
+            // Deal granularity: `deal_group` consecutive ranks (= neighbouring pixels of equal cost) stay
+            // in one pool, the groups go round-robin over the block's pools.  Coherent groups mean fewer
+            // distinct spheres pass the screen per wave (8.9 exact blocks per wave-iteration with single
+            // ranks vs 3.6 in tile order); mixed costs in a pool let a heavy pixel finish in the fast
+            // cooperative mode, which is what small shards need.  Measured (profiles/r01_deal_group_sweep.txt):
+            // full frame 24.1 -> 22.5 ms with 16-32, half frame 14.7 -> 14.0 with 8, quarter and eighth
+            // frames are fastest with 1.
+            const double pools_per_wave = (double)total_pools / (double)resident_waves;
+            const int deal_group = pools_per_wave >= 5.0 ? 16 : (pools_per_wave >= 2.5 ? 8 : 1);
+            const int scatter_blocks = ((p.W + 63) / 64) * ((h->local_rows + 63) / 64);   // one per 64 x 64 super-tile
+            hipLaunchKernelGGL(cost_scatter_kernel, dim3(scatter_blocks), dim3(1024), 0, h->stream, h->cost, p.W, h->local_rows, start, fill, h->order,
+                               pools_per_block, total_pools, deal_group);
             HIP_TRY(h, hipGetLastError());
             // ---- phase B: samples [SA, S) in that order
             p.s_begin = SA; p.mid_in = h->mid; p.order = h->order;

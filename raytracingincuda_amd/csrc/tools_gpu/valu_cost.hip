@@ -141,7 +141,7 @@ int main() {
     const int cus = p.multiProcessorCount;
     const double clock_hz = p.clockRate * 1e3;
     printf("{\"device\": \"%s\", \"cus\": %d, \"nominal_clock_mhz\": %d, \"unit\": \"nominal-clock cycles per wave-instruction per SIMD\"", p.gcnArchName, cus, p.clockRate / 1000);
-    for (int bpc : {5, 8}) {
+    for (int bpc : {1, 2, 5, 8}) {
         printf(", \"waves_per_simd_%d\": {", bpc);
         bool first = true;
 #define X(ID, NAME, TEXT, N) printf("%s\"" #NAME "\": %.2f", first ? "" : ", ", run<ID>(bpc, cus, N, clock_hz)); first = false;
