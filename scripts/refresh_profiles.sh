@@ -24,4 +24,8 @@ rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write_f64" -o pmc --output-format csv --
 echo "pmc done"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d "$OUT/pmc_sq" -o pmc --output-format csv -- python3 "$ROOT/scripts/one_render.py" --sched 2 --reps 3 > "$OUT/pmc_sq.log" 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d "$OUT/pmc_sq2" -o pmc --output-format csv -- python3 "$ROOT/scripts/one_render.py" --sched 2 --reps 3 > "$OUT/pmc_sq2.log" 2>&1
+cd "$ROOT"
+if [ -f raytracingincuda_amd/lib/librtiow_hip_stats.so ]; then python3 scripts/path_stats_probe.py > "$OUT/path_stats.json"; fi
+python3 scripts/scaling_probe.py > "$OUT/scaling_estimate.jsonl"
+python3 scripts/accounting_probe.py > "$OUT/accounting.jsonl"
 echo "all done"

@@ -43,3 +43,7 @@ for d in ("pmc_sq", "pmc_sq2"):
 json.dump({"config": "scene 3 1920x1080 100spp 50b fp32, sorted schedule; mean per dispatch", "counters": sq},
           open(os.path.join(dst, "%s_pmc_sq_final.json" % tag), "w"), indent=1)
 print(json.dumps(sq.get("main", {}), indent=1))
+
+for name, out in (("path_stats.json", "path_stats.json"), ("scaling_estimate.jsonl", "scaling_estimate_single_gpu.jsonl"), ("accounting.jsonl", "accounting_by_age_class.jsonl")):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, out)))
