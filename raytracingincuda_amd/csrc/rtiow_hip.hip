@@ -722,13 +722,6 @@ __device__ __forceinline__ void hit_world_coop(const RenderParams<T>& p, const T
     if (alive) { closest = rt; hit = ri; }
 }
 
-template <class T>
-__device__ __forceinline__ void load_rng(const RenderParams<T>& p, size_t lp, Rng& rs) {   // camera.h:136
-    const size_t npix = (size_t)p.W * p.local_rows;
-    rs.v0 = p.rng[0 * npix + lp]; rs.v1 = p.rng[1 * npix + lp]; rs.v2 = p.rng[2 * npix + lp];
-    rs.v3 = p.rng[3 * npix + lp]; rs.v4 = p.rng[4 * npix + lp]; rs.d = p.rng[5 * npix + lp];
-}
-
 // camera.h:167-171, color.h:10-13.  The RNG state is deliberately not written back.
 template <class T>
 __device__ __forceinline__ void store_pixel(const RenderParams<T>& p, size_t lp, V3<T> acc) {
@@ -1389,9 +1382,18 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     p.seg_counter = seg_counter ? seg_counter + 1 : nullptr;     // [0] prepass launch, [1] main (or only) launch
     const bool persistent = h->schedule != RTIOW_SCHED_STATIC;
     const int threads = bx * by;
-    const bool lds_source = h->scene_source != RTIOW_SCENE_SCALAR;
-    if (h->scene_source == RTIOW_SCENE_LDS && h->screen_dirty) { int rc = build_screen_table<T>(h); if (rc) return rc; }
+    // A scene whose tables do not fit the CU's LDS next to the drain scratch (several thousand
+    // spheres) is read through the scalar cache instead of failing: same image, exact loop.
+    const size_t coop_scratch = persistent ? (size_t)((threads + 63) / 64) * 64 * sizeof(CoopSlot<T>) : 0;
+    bool lds_source = h->scene_source != RTIOW_SCENE_SCALAR;
+    int effective_source = h->scene_source;
+    if (lds_source && (sizeof(T) + (h->scene_source == RTIOW_SCENE_LDS ? sizeof(float) : 0)) * 4 * (size_t)h->n_padded + coop_scratch > 160 * 1024) {
+        lds_source = false;
+        effective_source = RTIOW_SCENE_SCALAR;
+    }
+    if (lds_source && h->scene_source == RTIOW_SCENE_LDS && h->screen_dirty) { int rc = build_screen_table<T>(h); if (rc) return rc; }
     fill_screen_params<T>(p, h);
+    if (!lds_source) p.use_screen = 0;
     size_t lds = lds_source ? sizeof(T) * 4 * (size_t)h->n_padded : 0;
     p.screen_offset = (int)lds;
     if (p.use_screen) lds += sizeof(float) * 4 * (size_t)h->n_padded;
@@ -1504,7 +1506,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         h->stats.sgprs = 0;
         h->stats.lds_bytes = (int)(lds + fa.sharedSizeBytes);
         h->stats.block_x = bx; h->stats.block_y = by;
-        h->stats.scene_source = h->scene_source;
+        h->stats.scene_source = effective_source;
         h->stats.schedule = h->schedule;
         h->stats.grid_blocks = (int)(grid.x * grid.y);
         h->stats.phases = phases;

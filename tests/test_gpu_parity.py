@@ -150,6 +150,30 @@ def test_block_shapes_and_scene_sources_give_the_same_image(rt, oracle):
         assert _same_bits(_render(rt, 64, 3, 50, 30, 2, 12, threads, rt.SCENE_SCALAR), want64)
 
 
+def test_scene_larger_than_lds_falls_back_to_scalar_loads(rt, oracle):
+    """6000 spheres need 192 KB of fp32 tables: more than a CU's LDS.  The default source then reads
+    the tables through the scalar cache (stats say so) and the image still equals the oracle's."""
+    rng = np.random.default_rng(7)
+    n = 6000
+    base = compact(oracle.build_scene(3, 32))
+    cr = np.zeros((n, 4), np.float32); af = np.zeros((n, 4), np.float32)
+    cr[0] = base["center_radius"][0]; af[0] = base["albedo_fuzz"][0]                  # the ground
+    cr[1:, 0] = rng.uniform(-40, 40, n - 1); cr[1:, 2] = rng.uniform(-40, 40, n - 1); cr[1:, 1] = 0.2; cr[1:, 3] = 0.2
+    af[1:, :3] = rng.uniform(0.1, 0.9, (n - 1, 3)); af[1:, 3] = rng.uniform(0, 0.5, n - 1)
+    ty = rng.choice([0, 1, 2], n, p=[0.8, 0.15, 0.05]).astype(np.int32); ty[0] = 0
+    scene = {"center_radius": cr, "albedo_fuzz": af, "refraction_index": np.full(n, 1.5, np.float32), "type": ty,
+             "valid": np.ones(n, np.int32)}
+    W, H, S, B = 48, 32, 2, 8
+    cam = rt.camera(32, W, H, S, B)
+    want, _ = oracle.render(32, scene, cam, 1227)
+    for sched in (rt.SCHED_SORTED, rt.SCHED_STATIC):
+        with rt.Renderer(0, 32) as r:
+            r.set_camera(cam); r.set_scene(scene); r.set_schedule(sched); r.init_rng(1227)
+            r.render(0)
+            assert r.stats()["scene_source"] == rt.SCENE_SCALAR and r.stats()["num_spheres"] == n
+            assert _same_bits(r.read_framebuffer(), want), sched
+
+
 def test_per_launch_timing_and_segment_counts(rt):
     """The sorted schedule's two launches are timed and counted separately (bench.py's roofline is
     the main launch): event times nest inside the render time, segment counts add up."""
