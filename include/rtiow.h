@@ -47,8 +47,8 @@ extern "C" {
  * STATIC     = the reference's launch geometry: grid of T x T blocks, one lane per pixel
  *              (main.cu:137-139, camera.h:131-134);
  * PERSISTENT = resident waves pull 64-pixel pools from a global counter and hand a new pixel
- *              to every lane the moment it finishes one (--threads still sets the
- *              workgroup size T x T). */
+ *              to every lane the moment it finishes one (lanes are not pixels here, so
+ *              --threads has no effect: workgroups are always four waves). */
 #define RTIOW_SCHED_STATIC     0
 #define RTIOW_SCHED_PERSISTENT 1
 /* SORTED = PERSISTENT in two phases: the first few samples of every pixel are rendered and
@@ -136,7 +136,8 @@ int rtiow_init_rng(rtiow_handle h, uint64_t seed);
 
 /* ---- render: replaces render<<<dimGrid,dimBlock>>> + sync (main.cu:334-341).
  * threads_per_block_row is the reference's --threads (block = T x T pixels, main.cu:137-139;
- * the grid is ceil-divided, unlike main.cu:137-138).  0 selects the library's own tiling.
+ * the grid is ceil-divided, unlike main.cu:137-138): it shapes the launch of RTIOW_SCHED_STATIC and
+ * is accepted and ignored by the dynamic schedules.  0 selects the library's own tiling.
  * kernel_ms (may be NULL) receives the HIP-event time around the kernel only; passing NULL
  * makes the call asynchronous on the handle's stream. */
 int rtiow_render(rtiow_handle h, int threads_per_block_row, float* kernel_ms);

@@ -29,6 +29,7 @@ struct Options {
     int scene_source = RTIOW_SCENE_LDS;
     bool stats = false;
     bool binary_ppm = false;
+    int schedule = RTIOW_SCHED_SORTED;
 };
 
 const char* kUsage =
@@ -71,7 +72,7 @@ Options parse(int argc, char** argv) {
         if (eq != std::string::npos) { value = name.substr(eq + 1); name = name.substr(0, eq); have_value = true; }
         if (name == "stats") { o.stats = true; continue; }
         const bool known = name == "scene_id" || name == "width" || name == "height" || name == "samples" ||
-                           name == "bounces" || name == "threads" || name == "scene_source" || name == "ppm_format";
+                           name == "bounces" || name == "threads" || name == "scene_source" || name == "ppm_format" || name == "schedule";
         if (!known) parse_abort("Option '" + name + "' does not exist");
         if (!have_value) {
             if (k + 1 >= argc) parse_abort("Option '" + name + "' is missing an argument");
@@ -80,6 +81,13 @@ Options parse(int argc, char** argv) {
         if (name == "scene_source") {
             if (value == "lds") o.scene_source = RTIOW_SCENE_LDS;
             else if (value == "scalar") o.scene_source = RTIOW_SCENE_SCALAR;
+            else parse_abort("Argument '" + value + "' failed to parse");
+            continue;
+        }
+        if (name == "schedule") {
+            if (value == "sorted") o.schedule = RTIOW_SCHED_SORTED;
+            else if (value == "persistent") o.schedule = RTIOW_SCHED_PERSISTENT;
+            else if (value == "static") o.schedule = RTIOW_SCHED_STATIC;
             else parse_abort("Argument '" + value + "' failed to parse");
             continue;
         }
@@ -134,6 +142,7 @@ int main(int argc, char** argv) {
     }
     check(h, rtiow_set_camera(h, cam));
     check(h, rtiow_set_scene_source(h, opt.scene_source));
+    check(h, rtiow_set_schedule(h, opt.schedule, 0));
 
     // world creation (main.cu:142-321)
     const int slots = rtiow_host_scene_slots(opt.scene_id);

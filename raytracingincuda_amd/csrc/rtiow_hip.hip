@@ -1515,7 +1515,12 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     return 0;
 }
 
-void block_shape(int T, int& bx, int& by, int& wave_tiles) {
+// T (the reference's --threads) shapes the workgroup of RTIOW_SCHED_STATIC, whose lanes ARE the
+// pixels of a T x T block.  The dynamic schedules hand pixels to lanes themselves, so a workgroup
+// there is just four waves whatever T says (measured with T as the workgroup size: 69 / 22.3 / 22.3 /
+// 33 / 26 ms for T = 4 / 8 / 16 / 24 / 32 -- partly filled waves and uneven SIMD packing).
+void block_shape(int T, bool static_schedule, int& bx, int& by, int& wave_tiles) {
+    if (!static_schedule) T = 0;
     if (T == 0) { bx = 16; by = 16; wave_tiles = 1; }       // library tiling: 4 waves, each an 8x8 tile
     else if (T == 8) { bx = 8; by = 8; wave_tiles = 1; }    // == the reference's 8x8 block (one wave)
     else { bx = T; by = T; wave_tiles = 0; }                 // the reference's T x T row-major block
@@ -1682,7 +1687,7 @@ int rtiow_render(rtiow_handle h, int threads_per_block_row, float* kernel_ms) {
     if (rc) return rc;
     if (h->local_rows == 0) { if (kernel_ms) *kernel_ms = 0; return 0; }
     int bx, by, wave_tiles;
-    block_shape(T, bx, by, wave_tiles);
+    block_shape(T, h->schedule == RTIOW_SCHED_STATIC, bx, by, wave_tiles);
     if (kernel_ms) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));                     // main.cu:334
     h->time_phases = kernel_ms != nullptr;
     if (h->precision == 32) rc = launch_render<float>(h, h->cam32, bx, by, wave_tiles);
@@ -1724,7 +1729,7 @@ int rtiow_count_segments(rtiow_handle h, int threads_per_block_row, uint64_t* se
     HIP_TRY(h, hipMalloc((void**)&d, 2 * sizeof *d));
     HIP_TRY(h, hipMemsetAsync(d, 0, 2 * sizeof *d, h->stream));
     int bx, by, wave_tiles;
-    block_shape(T, bx, by, wave_tiles);
+    block_shape(T, h->schedule == RTIOW_SCHED_STATIC, bx, by, wave_tiles);
     if (h->precision == 32) rc = launch_render<float>(h, h->cam32, bx, by, wave_tiles, d);
     else rc = launch_render<double>(h, h->cam64, bx, by, wave_tiles, d);
     if (rc) { (void)hipFree(d); return rc; }

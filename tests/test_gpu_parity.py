@@ -174,6 +174,16 @@ def test_scene_larger_than_lds_falls_back_to_scalar_loads(rt, oracle):
             assert _same_bits(r.read_framebuffer(), want), sched
 
 
+def test_threads_shapes_only_the_static_schedule(rt):
+    with rt.Renderer(0, 32) as r:
+        r.set_camera(rt.camera(32, 96, 64, 2, 8)); r.set_scene(rt.build_scene(3, 32)); r.init_rng(1227)
+        for T in (4, 24, 32):
+            r.set_schedule(rt.SCHED_SORTED); r.render(T)
+            assert (r.stats()["block_x"], r.stats()["block_y"]) == (16, 16)
+            r.set_schedule(rt.SCHED_STATIC); r.render(T)
+            assert (r.stats()["block_x"], r.stats()["block_y"]) == (T, T)
+
+
 def test_per_launch_timing_and_segment_counts(rt):
     """The sorted schedule's two launches are timed and counted separately (bench.py's roofline is
     the main launch): event times nest inside the render time, segment counts add up."""
@@ -281,6 +291,13 @@ def test_executable_is_a_drop_in(rt, oracle, tmp_path):
     levels = np.array(rt.format_ppm(want).split()[4:], dtype=np.uint8)
     assert np.array_equal(np.frombuffer(raw[14:], np.uint8), levels)
     (tmp_path / "p6" / name).unlink(); sub.rmdir()
+    # --schedule static = the reference's launch geometry (one lane per pixel of a --threads^2 block): same file
+    sub = tmp_path / "static"; sub.mkdir()
+    rs = subprocess.run([exe, "--scene_id", "1", "--width=160", "--height", "96", "--samples", "4", "--bounces=25", "--threads", "8",
+                         "--schedule", "static"], capture_output=True, text=True, cwd=str(sub))
+    assert rs.returncode == 0, rs.stderr
+    assert open(str(sub / name), "rb").read() == rt.format_ppm(want)
+    (sub / name).unlink(); sub.rmdir()
     # defaults (main.cu:45-54) and the double variant's name (GlobalDouble main.cu:351)
     exe64 = exe.replace("float", "double")
     r = subprocess.run([exe64, "--scene_id=3", "--samples=1", "--bounces=2"], capture_output=True, text=True, cwd=str(tmp_path))
