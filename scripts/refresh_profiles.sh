@@ -13,6 +13,10 @@ echo "bench fp32 done"
 python3 bench.py --steps 10 --warmup 2 --precision 64 --no-cpu-baseline > "$OUT/bench_n1_f64.json"
 python3 bench.py --steps 5 --warmup 2 --scene_id 1 --no-cpu-baseline > "$OUT/bench_n1_scene1.json"
 python3 bench.py --steps 10 --warmup 2 --schedule static --threads 8 --no-cpu-baseline > "$OUT/bench_n1_static_t8.json"
+# the other BASELINE.json configs: [1] scene 1 320x192 10 spp 25 bounces, [2] 1280x720, [4] fp64 at 500 spp
+python3 bench.py --steps 20 --warmup 3 --scene_id 1 --width 320 --height 192 --samples 10 --bounces 25 --threads 8 --no-cpu-baseline > "$OUT/bench_config2_scene1_320x192.json"
+python3 bench.py --steps 20 --warmup 3 --width 1280 --height 720 --threads 8 --no-cpu-baseline > "$OUT/bench_config3_1280x720.json"
+python3 bench.py --steps 5 --warmup 1 --precision 64 --samples 500 --no-cpu-baseline > "$OUT/bench_config5_f64_500spp.json"
 echo "bench variants done"
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/ktrace" -o kt --output-format csv -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/ktrace.log"

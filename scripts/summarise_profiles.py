@@ -11,7 +11,11 @@ def last_json(path):
     return json.loads(open(path).read().strip().splitlines()[-1])
 
 for name, out in (("bench_n1.json", "bench_n1"), ("bench_n1_f64.json", "bench_n1_f64"), ("bench_n1_scene1.json", "bench_n1_scene1"),
-                  ("bench_n1_static_t8.json", "bench_n1_static_t8"), ("bench_under_rocprof.json", "bench_under_rocprof")):
+                  ("bench_n1_static_t8.json", "bench_n1_static_t8"), ("bench_under_rocprof.json", "bench_under_rocprof"),
+                  ("bench_config2_scene1_320x192.json", "bench_config2_scene1_320x192"), ("bench_config3_1280x720.json", "bench_config3_1280x720"),
+                  ("bench_config5_f64_500spp.json", "bench_config5_f64_500spp")):
+    if not os.path.exists(os.path.join(src, name)):
+        continue
     json.dump(last_json(os.path.join(src, name)), open(os.path.join(dst, "%s_%s.json" % (tag, out)), "w"), indent=1)
 stats = glob.glob(os.path.join(src, "ktrace", "**", "*kernel_stats.csv"), recursive=True)[0]
 shutil.copy(stats, os.path.join(dst, "%s_kernel_stats.csv" % tag))
