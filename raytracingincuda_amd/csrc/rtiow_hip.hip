@@ -179,6 +179,7 @@ template <class T> struct RenderParams {
     const int* __restrict__ order;    // slot -> local pixel (or -1), nullptr: 8x8 tiles bottom-up
     int total_slots;
     int first_pools;                  // 1: wave w starts with pool w (the work counter then starts at the wave count)
+    int lane_cap;                     // lanes of a wave that take pixels (64; fewer when the launch is underfilled, see launch_render)
     unsigned long long* timeline;     // COUNT variant, optional: per wave {t_start, t_exhausted, t_end, iters_normal, iters_coop, pixels, 0, 0}
 };
 
@@ -884,16 +885,18 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
     // p.first_pools: wave w takes pool w first and the counter starts behind them.  Workgroups are
     // dispatched in blockIdx order and the SIMD arbiter favours older waves, so this puts the
     // heaviest block of the cost-sorted order on the waves that will run fastest.
-    int first_pool = p.first_pools ? ((int)blockIdx.x * (int)((blockDim.x + 63) >> 6) + (int)(threadIdx.x >> 6)) * POOL : -1;
+    const int take = p.lane_cap;                 // slots per refill: 64, fewer in an underfilled launch
+    int first_pool = p.first_pools ? ((int)blockIdx.x * (int)((blockDim.x + 63) >> 6) + (int)(threadIdx.x >> 6)) * take : -1;
     unsigned long long t_start = 0, t_exh = 0;
     unsigned int it_normal = 0, it_coop = 0, n_pixels = 0;
     if (COUNT) t_start = __builtin_amdgcn_s_memrealtime();
+    const bool takes_pixels = (int)(threadIdx.x & 63u) < p.lane_cap;
     const int lanes_left = (int)blockDim.x - (int)(threadIdx.x & ~63u);
     const int wave_lanes = lanes_left < 64 ? lanes_left : 64;   // partial last wave of a T x T block
 
     for (;;) {
-        if (!exhausted && __builtin_amdgcn_ballot_w64(!alive) != 0) {
-            bool want = !alive;
+        if (!exhausted && __builtin_amdgcn_ballot_w64(!alive && takes_pixels) != 0) {
+            bool want = !alive && takes_pixels;
             PATH_STAT(PS_REFILL);
             for (;;) {
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
@@ -904,11 +907,11 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
                         base = first_pool;
                         first_pool = -1;
                     } else {
-                        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) base = (int)atomicAdd(p.work_counter, (unsigned)POOL);
+                        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) base = (int)atomicAdd(p.work_counter, (unsigned)take);
                         base = __builtin_amdgcn_readfirstlane(base);
                     }
                     if (base >= total_slots) { exhausted = true; if (COUNT) t_exh = __builtin_amdgcn_s_memrealtime(); break; }
-                    pool_next = base; pool_end = base + POOL;
+                    pool_next = base; pool_end = base + take;
                 }
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 const int avail = pool_end - pool_next;
@@ -957,7 +960,7 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
         if (alive && fresh) { gen_primary(p, i, j, st.rs, st.O, st.D, st.sky_uy); st.atten = {1, 1, 1}; fresh = false; }
         bool terminated = false;
         V3<T> col = {0, 0, 0};
-        if (exhausted && 2 * __builtin_popcountll(alive_mask) <= wave_lanes) {
+        if ((exhausted || 2 * p.lane_cap <= wave_lanes) && 2 * __builtin_popcountll(alive_mask) <= wave_lanes) {
             // drain tail: idle lanes share the survivors' sphere loops (hit_world_coop)
             if (COUNT) ++it_coop;
             const bool need_hit = alive && st.depth < p.B;
@@ -1380,6 +1383,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     RenderParams<T> p = make_params<T>(h, cam);
     p.bx = bx; p.by = by; p.wave_tiles = wave_tiles;
     p.seg_counter = seg_counter ? seg_counter + 1 : nullptr;     // [0] prepass launch, [1] main (or only) launch
+    p.lane_cap = 64;
     const bool persistent = h->schedule != RTIOW_SCHED_STATIC;
     const int threads = bx * by;
     // A scene whose tables do not fit the CU's LDS next to the drain scratch (several thousand
@@ -1427,9 +1431,22 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             if (cap < per_cu) per_cu = cap;
         }
         const long long tile_slots = (long long)((p.W + 7) / 8) * ((h->local_rows + 7) / 8) * POOL;
+        // Underfilled launch (fewer 64-pixel pools than resident waves: small frames): let only the first
+        // `lane_cap` lanes of every wave take pixels.  More waves are busy, each permanently in the
+        // cooperative mode, where its idle lanes split the sphere loops of the live ones: a trip gets
+        // shorter, and with so little work the frame is as long as its longest chain of trips.
+        // Measured (profiles/r01_lane_cap_sweep.txt): scene 1 320x192x10 2.27 -> 1.06 ms, 640x384x100
+        // 19.4 -> 17.0 ms; frames with at least one pool per wave are unchanged (cap 64).
+        int lane_cap = 64;
+        {
+            const long long pools = tile_slots / POOL, waves = (long long)h->num_cus * per_cu * waves_per_block;
+            while (lane_cap > 8 && pools * (64 / lane_cap) < waves) lane_cap >>= 1;   // the largest share that keeps every wave busy
+        }
+        p.lane_cap = lane_cap;
         long long blocks = (long long)h->num_cus * per_cu;
-        const long long useful = (tile_slots + (long long)waves_per_block * POOL - 1) / ((long long)waves_per_block * POOL);
-        if (blocks > useful) blocks = useful;               // never more waves than 64-pixel pools
+        const long long per_block = (long long)waves_per_block * lane_cap;
+        const long long useful = (tile_slots + per_block - 1) / per_block;
+        if (blocks > useful) blocks = useful;               // never more waves than lane_cap-pixel shares of the pools
         grid = dim3((unsigned)blocks);
 
         const int npix = p.W * h->local_rows;
@@ -1489,7 +1506,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             p.total_slots = total_pools * POOL;
             p.work_counter = h->work_counter + 1;
             p.first_pools = 1;
-            const unsigned counter_start = (unsigned)resident_waves * POOL;
+            const unsigned counter_start = (unsigned)resident_waves * (unsigned)lane_cap;
             HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)(h->work_counter + 1), (int)counter_start, 1, h->stream));
         }
     } else {
