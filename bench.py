@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--threads", type=int, default=0, help="reference --threads (block T x T); 0 = library tiling")
     ap.add_argument("--scene_source", default="lds", choices=("lds", "scalar"))
     ap.add_argument("--schedule", default="sorted", choices=("sorted", "persistent", "static"))
-    ap.add_argument("--strip_rows", type=int, default=8)
+    ap.add_argument("--strip_rows", type=int, default=0, help="rows per interleaved strip; 0 = 8 for N <= 2, 2 for N >= 4 (profiles/r01_strip_rows_sweep.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -115,6 +115,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if args.strip_rows <= 0:
+        args.strip_rows = 8 if world <= 2 else 2
     import raytracingincuda_amd as rt
     from raytracingincuda_amd.distributed import StripGather
 
