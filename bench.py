@@ -208,7 +208,7 @@ def main():
             "kernel_ms_mean_max_over_ranks": round(kernel_mean_max, 4),
             "segments_per_ray": round(segments_total / rays, 4),
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args) if world == 1 else None,   # PMC passes are single-GPU, full frame
+                         "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args) if world == 1 and args.schedule == "sorted" else None,   # the PMC passes: one GPU, full frame, default schedule
                          "kernel": "%s<%s>" % ("render_kernel" if args.schedule == "static" else "render_persistent_kernel", "float" if prec == 32 else "double"),
                          "launch_ms_mean": round(mms, 4), "launch_ms_min": round(float(np.min(main_ms)), 4),
                          "algorithmic_flops_per_launch": flops, "segments_in_launch": int(st["segments_main"]),
