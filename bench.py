@@ -11,7 +11,7 @@ row strips, then one RCCL gather of the strips to rank 0 -- the gather is inside
 
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline      dominant kernel = the main launch of the render (render_persistent_kernel; the
-                sorted schedule's prepass of 4 of the 100 samples is a separate, named launch)
+                sorted schedule's prepass of 3 of the 100 samples is a separate, named launch)
                 against the VALU peak: algorithmic flops of that launch = segments*(23*N+120) +
                 rays*60 (segments counted per launch on the device by
                 rtiow_count_segments) / its mean HIP-event time over the timed steps.  The same

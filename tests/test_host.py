@@ -142,6 +142,13 @@ def test_cli_unknown_option_aborts_like_uncaught_cxxopts(native):
     assert r.returncode == -6 and r.stdout == ""
 
 
+def test_cli_extension_flags_reject_bad_values(native):
+    # --schedule / --ppm_format / --scene_source are additions; a bad value fails like a bad integer does
+    for flag, bad in (("--schedule", "bogus"), ("--ppm_format", "p9"), ("--scene_source", "texture")):
+        r = subprocess.run([_exe(native), "--scene_id", "1", flag, bad], capture_output=True, text=True)
+        assert r.returncode == -6 and "failed to parse" in r.stderr and r.stdout == ""
+
+
 def test_cli_device_failure_keeps_stdout_empty(native):
     import torch
     if torch.cuda.is_available():
