@@ -58,6 +58,19 @@ def parse():
     return ap.parse_args()
 
 
+def host_cpu():
+    """Model name and logical core count of the host the CPU baseline runs on."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"cpu_model": model, "host_logical_cores": os.cpu_count()}
+
+
 def cpu_baseline(args):
     """Reference serial tracer on a bounded sample: the same scene, camera, spp and bounces
     on a 1/16-area frame (W/4 x H/4), 1 thread.  ~10-30 s of CPU work."""
@@ -72,14 +85,14 @@ def cpu_baseline(args):
         r = subprocess.run([drv, str(args.scene_id), str(W), str(H), str(S), str(B)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
         dt = time.perf_counter() - t0
         if r.returncode == 0 and r.stdout.startswith(b"P3"):
-            return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
-                    "sample": sample + "; reference src/InOneWeekend headers built by oracle/Makefile", "seconds": dt}
+            return dict({"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
+                         "sample": sample + "; reference src/InOneWeekend headers built by oracle/Makefile", "seconds": dt}, **host_cpu())
     from tests.oracle_lib import Oracle   # the oracle is only ever the checker / CPU baseline
     orc = Oracle()
     t0 = time.perf_counter()
     orc.render_serial(args.scene_id, W, H, S, B)
     dt = time.perf_counter() - t0
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": sample + "; oracle serial port", "seconds": dt}
+    return dict({"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": sample + "; oracle serial port", "seconds": dt}, **host_cpu())
 
 
 def pmc_traffic(args):
