@@ -172,6 +172,10 @@ int rtiow_debug_read_rng(rtiow_handle h, uint32_t* host_states, size_t count_wor
  * pixels taken, 0, 0}. */
 int rtiow_debug_timeline(rtiow_handle h, int threads_per_block_row, uint64_t* out_words, size_t cap_words, int* waves);
 int rtiow_debug_ops(rtiow_handle h, int op, size_t n, const void* a, const void* b, const void* c, void* out);
+/* The 32 XORWOW subsequence-jump matrices A^(2^(67+b)) (160 x 5 words each) as the library builds
+ * them: from its committed constant A^(2^67), or from_scratch != 0 from the one-step matrix A.
+ * Host arithmetic only (no GPU needed).  Returns the number of matrices. */
+int rtiow_debug_jump_matrices(uint32_t* out_words, size_t cap_words, int from_scratch);
 
 #ifdef __cplusplus
 }

@@ -71,7 +71,7 @@ HIP_SYMBOLS = [
     "rtiow_set_scene", "rtiow_set_camera", "rtiow_set_shard", "rtiow_local_rows", "rtiow_local_row_map",
     "rtiow_init_rng", "rtiow_render", "rtiow_count_segments", "rtiow_bind_framebuffer", "rtiow_framebuffer_device_ptr",
     "rtiow_read_framebuffer", "rtiow_set_scene_source", "rtiow_set_schedule", "rtiow_get_stats", "rtiow_synchronize",
-    "rtiow_debug_read_rng", "rtiow_debug_timeline", "rtiow_debug_ops",
+    "rtiow_debug_read_rng", "rtiow_debug_timeline", "rtiow_debug_ops", "rtiow_debug_jump_matrices",
 ]
 HOST_SYMBOLS = [
     "rtiow_host_scene_slots", "rtiow_host_build_scene", "rtiow_host_camera", "rtiow_host_ppm_filename",

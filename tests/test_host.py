@@ -142,6 +142,21 @@ def test_cli_unknown_option_aborts_like_uncaught_cxxopts(native):
     assert r.returncode == -6 and r.stdout == ""
 
 
+def test_committed_jump_constant_equals_the_matrix_power(native):
+    """xorwow_jump67.inc (A^(2^67), used to skip 67 of the 98 squarings per process) against the same 32
+    jump matrices derived from the one-step matrix A: host arithmetic of librtiow_hip.so, no GPU needed."""
+    import ctypes
+    lib = ctypes.CDLL(native.lib_paths()["hip"])
+    lib.rtiow_debug_jump_matrices.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t, ctypes.c_int]
+    n = 32 * 160 * 5
+    fast, scratch = (ctypes.c_uint32 * n)(), (ctypes.c_uint32 * n)()
+    assert lib.rtiow_debug_jump_matrices(fast, n, 0) == 32
+    assert lib.rtiow_debug_jump_matrices(scratch, n, 1) == 32
+    assert bytes(fast) == bytes(scratch)
+    assert len(set(bytes(fast)[k * 3200:(k + 1) * 3200] for k in range(32))) == 32     # 32 different matrices
+    assert lib.rtiow_debug_jump_matrices(fast, n - 1, 0) < 0                            # buffer too small
+
+
 def test_cli_extension_flags_reject_bad_values(native):
     # --schedule / --ppm_format / --scene_source are additions; a bad value fails like a bad integer does
     for flag, bad in (("--schedule", "bogus"), ("--ppm_format", "p9"), ("--scene_source", "texture")):
