@@ -38,8 +38,9 @@ extern "C" {
 
 /* Scene-table source selected for the sphere loop (the AMD analogue of the reference's
  * global / constant / texture variants, README.md:7-12). */
-#define RTIOW_SCENE_LDS       0 /* sphere list staged into LDS per workgroup (default); fp32 adds the
-                                 * 9-operation conservative screen in front of the exact test   */
+#define RTIOW_SCENE_LDS       0 /* sphere list staged into LDS per workgroup (default), with the packed-
+                                 * fp32 8-operation conservative screen in front of the exact test
+                                 * (both precisions)                                             */
 #define RTIOW_SCENE_SCALAR    1 /* wave-uniform scalar loads through the scalar cache, exact loop */
 #define RTIOW_SCENE_LDS_EXACT 2 /* LDS, the reference's 12-operation test on every sphere        */
 
@@ -51,10 +52,11 @@ extern "C" {
  *              --threads has no effect: workgroups are always four waves). */
 #define RTIOW_SCHED_STATIC     0
 #define RTIOW_SCHED_PERSISTENT 1
-/* SORTED = PERSISTENT in two phases: the first few samples of every pixel are rendered and
- * their path-segment counts recorded; the pixels are then ranked heavy-first into balanced
- * pools and the remaining samples rendered in that order (RNG state and colour sum carried
- * exactly, so the image is unchanged).  Removes the drain tail of late heavy pixels. Default. */
+/* SORTED = PERSISTENT in two launches: a prepass renders the first 3 samples of every pixel and
+ * records their path-segment counts; the pixels are then ranked heavy-first into balanced pools
+ * of neighbouring pixels and the main launch renders the remaining samples in that order (RNG
+ * state and colour sum carried exactly, so the image is unchanged).  Removes the drain tail of
+ * late heavy pixels.  Default. */
 #define RTIOW_SCHED_SORTED     2
 
 typedef struct rtiow_handle_s* rtiow_handle;

@@ -175,7 +175,7 @@ template <class T> struct RenderParams {
     // (SoA cost 630 MB of fetches per frame for 83 MB of state).
     const unsigned char* __restrict__ mid_in;   // main launch: state at sample s_begin (nullptr: rng_in, zero sum)
     unsigned char* __restrict__ mid_out;        // prepass: park the state (nullptr: final launch, the pixel is stored)
-    uint32_t* __restrict__ cost_out;  // phase A only: segments the pixel ran in this phase
+    uint32_t* __restrict__ cost_out;  // prepass only: segments the pixel ran in this launch
     const int* __restrict__ order;    // slot -> local pixel (or -1), nullptr: 8x8 tiles bottom-up
     int total_slots;
     int first_pools;                  // 1: wave w starts with pool w (the work counter then starts at the wave count)
@@ -415,7 +415,7 @@ __device__ __forceinline__ void exact_sphere_test_f32(const float* g, int s, V3<
     if (disc >= 0.0f) finish_sphere_test<float>(s, h, disc, a, closest, hit);                      // :48-57
 }
 
-// hit_world with a 9-operation SCREEN in front of the reference's 12-operation test (fp32).
+// hit_world with an 8-operation SCREEN (packed fp32) in front of the reference's 12-operation test.
 //
 // In exact arithmetic h = d.(C-O) = d.C - d.O and c = |C-O|^2 - r^2 = (|C|^2 - r^2) + |O|^2 - 2 O.C,
 // so with the per-ray constants k1 = d.O', k2 = |O'|^2, m = -2 O' (O' = O - centre) and the
@@ -761,7 +761,7 @@ __device__ __forceinline__ int global_row(int jl, int strip_rows, int nranks, in
 }
 
 // End of a pixel in one launch: the final phase writes the pixel
-// (camera.h:167-171); phase A of the sorted schedule parks the exact state instead.
+// (camera.h:167-171); the prepass of the sorted schedule parks the exact state instead.
 // Per-pixel hand-over record, read and written as 16-byte vectors: fp32 48 bytes, fp64 64 bytes.
 template <class T> struct MidState;
 template <> struct alignas(16) MidState<float>  { uint32_t v[5], d; float acc[3]; uint32_t pad[3]; };
@@ -922,7 +922,7 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
                 if (take) {
                     int jl;
                     bool valid;
-                    if (p.order) {                               // cost-sorted hand-out (phase B)
+                    if (p.order) {                               // cost-sorted hand-out (main launch of the sorted schedule)
                         const int px = p.order[slot];
                         valid = px >= 0;
                         jl = valid ? px / p.W : 0;
@@ -1465,7 +1465,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
 
         const int npix = p.W * h->local_rows;
         const int S = p.S;
-        // phase A length: enough samples to rank the pixels, a small share of the frame
+        // prepass length: enough samples to rank the pixels, a small share of the frame
         const int SA = S >= 64 ? 3 : (S >= 24 ? 2 : 0);   // measured on the headline config: 1 -> 25.5 ms, 2 -> 22.5, 3 -> 22.1, 4 -> 22.4, 8 -> 23.1
         p.work_counter = h->work_counter;
         p.s_begin = 0; p.s_end = S; p.rng_in = h->rng; p.mid_in = nullptr; p.mid_out = nullptr;
@@ -1479,9 +1479,9 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             if ((rc = ensure_buffer(h, &h->order, &h->order_bytes, (size_t)total_pools * POOL * sizeof(int)))) return rc;
             if ((rc = ensure_buffer(h, &h->sort_scratch, &h->sort_scratch_bytes, (size_t)3 * COST_BINS * sizeof(unsigned)))) return rc;
             if (prepare_only) return 0;                  // every table and buffer of this configuration now exists
-            // ---- phase A: samples [0, SA) in tile order through the same persistent kernel (the
-            // static kernel keeps only ~40 % of its lanes busy over 4 samples: 2.6 ms vs 1.4 ms
-            // measured); RNG state, colour sum and segment count are parked per pixel.
+            // ---- prepass: samples [0, SA) in tile order through the same persistent body (the static
+            // kernel keeps only ~40 % of its lanes busy over a few samples: 2.6 ms vs 1.4 ms measured
+            // for 4 samples); RNG state, colour sum and segment count are parked per pixel.
             RenderParams<T> pa = p;
             pa.s_end = SA; pa.mid_out = h->mid; pa.cost_out = h->cost;
             pa.seg_counter = seg_counter;
@@ -1516,7 +1516,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             hipLaunchKernelGGL(cost_scatter_kernel, dim3(scatter_blocks), dim3(1024), 0, h->stream, h->cost, p.W, h->local_rows, start, fill, h->order,
                                pools_per_block, total_pools, deal_group);
             HIP_TRY(h, hipGetLastError());
-            // ---- phase B: samples [SA, S) in that order
+            // ---- main launch: samples [SA, S) in that order
             p.s_begin = SA; p.mid_in = h->mid; p.order = h->order;
             p.total_slots = total_pools * POOL;
             p.work_counter = h->work_counter + 1;
