@@ -407,3 +407,27 @@ def test_full_size_properties(rt, oracle):
     for row in (0, 611, 1079):
         want, _ = _oracle(oracle, rt, 32, 3, W, H, S, B, rows=(row, row + 1))
         assert _same_bits(a[row:row + 1], want), row
+
+
+def test_bench_prints_one_contract_line(rt):
+    """bench.py's contract with the driver: exactly one JSON line on stdout with the agreed fields,
+    the roofline of the dominant launch and the CPU baseline (small frame so the CPU leg takes a second)."""
+    import json, sys
+    from tests.conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--width", "256", "--height", "144",
+                        "--samples", "64", "--bounces", "10"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 256 * 144 * 64 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["launch_ms_mean"] <= d["kernel_ms_mean"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and cb["sample"]

@@ -171,3 +171,14 @@ def test_cli_device_failure_keeps_stdout_empty(native):
     # main.cu:14-21: runtime failure -> message on stderr, exit(code), nothing on stdout (empty CSV cell)
     r = subprocess.run([_exe(native), "--scene_id=3", "--width=16", "--height=8"], capture_output=True, text=True)
     assert r.returncode != 0 and r.stdout == "" and "HIP_SAFE_CALL" in r.stderr
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """No CPU fallback anywhere: bench.py says so and exits non-zero when no GPU is visible."""
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from tests.conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout) and not r.stdout.strip().startswith("{")
