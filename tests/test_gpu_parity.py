@@ -431,3 +431,24 @@ def test_bench_prints_one_contract_line(rt):
     assert rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["launch_ms_mean"] <= d["kernel_ms_mean"]
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and cb["sample"]
+
+
+def test_bench_two_rank_rehearsal(rt):
+    """bench.py --gpus 2 launched the way the driver launches it (torch.distributed.run, one rank per
+    process); with a single GPU the ranks share device 0 and gather over gloo (RTIOW_BENCH_BACKEND).
+    Checks the rank-0 line: whole-job value, strong scaling, sharding description, no traffic figure."""
+    import json, sys
+    from tests.conftest import ROOT
+    env = dict(os.environ, RTIOW_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--width", "256", "--height", "144", "--samples", "64", "--bounces", "10"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["backend"] == "gloo" and "strips" in d["config"]["sharding"]
+    assert abs(d["value"] - 256 * 144 * 64 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]
+    assert d["roofline"]["traffic"] is None and "cpu_baseline" not in d
+    assert 1.5 < d["segments_per_ray"] < 3.5            # summed over both ranks' shards
