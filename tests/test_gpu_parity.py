@@ -452,3 +452,26 @@ def test_bench_two_rank_rehearsal(rt):
     assert abs(d["value"] - 256 * 144 * 64 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]
     assert d["roofline"]["traffic"] is None and "cpu_baseline" not in d
     assert 1.5 < d["segments_per_ray"] < 3.5            # summed over both ranks' shards
+
+
+def test_degenerate_sizes_and_depths(rt, oracle):
+    """Frames smaller than a tile or a wave, one sample, no bounces: every schedule still equals the
+    oracle bit for bit (lane cap, padded pools and the unsorted / sorted switch all depend on the size)."""
+    cases = [(1, 1, 1, 0), (1, 1, 3, 1), (1, 70, 2, 5), (70, 1, 2, 5), (9, 9, 1, 50), (65, 3, 24, 2), (8, 8, 64, 3), (33, 17, 70, 1)]
+    for prec in (32, 64):
+        for W, H, S, B in cases:
+            want, _ = _oracle(oracle, rt, prec, 3, W, H, S, B)
+            for sched in (rt.SCHED_SORTED, rt.SCHED_PERSISTENT, rt.SCHED_STATIC):
+                got = _render(rt, prec, 3, W, H, S, B, threads=8, sched=sched)
+                assert _same_bits(got, want), (prec, W, H, S, B, sched)
+    # odd shard splits of a small frame: more ranks than strips, one-row strips
+    want, _ = _oracle(oracle, rt, 32, 3, 40, 11, 30, 8)
+    for n, strip in ((5, 8), (3, 1), (11, 1), (4, 3)):
+        full = np.zeros_like(want)
+        for rank in range(n):
+            with rt.Renderer(0, 32) as r:
+                r.set_camera(rt.camera(32, 40, 11, 30, 8)); r.set_scene(rt.build_scene(3, 32)); r.set_shard(rank, n, strip); r.init_rng(1227)
+                r.render(0)
+                if r.local_rows:
+                    rt.place_rows(full, r.read_framebuffer(), rank, n, strip)
+        assert _same_bits(full, want), (n, strip)
