@@ -37,7 +37,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -373,23 +375,186 @@ inline bool hit_world(const World<T>& w, V3<T> O, V3<T> D, T tmin, T tmax, Hit<T
 }
 
 // =====================================================================================
-// CUDA-semantics render (camera.h:73-172)
+// ONE scatter / sky / ray_color implementation for both semantics.
+//
+// Everything after hit_world -- material dispatch, the three scatters, random_unit_vector,
+// Schlick, the sky blend, the bounce loop -- exists ONCE below, as templates over a POLICY
+// that holds only what differs between the reference's two programs:
+//
+//                        SerialPolicy (src/InOneWeekend)         CudaPolicy<T> (src/Global{Float,Double}CUDA...)
+//   real type            double                                  T = float | double
+//   a*b+c contraction    none (g++ -O3, x86-64, no -mfma)        explicit fma at the DESIGN.md places
+//   RNG                  one glibc rand() stream, [0,1)          per-pixel XORWOW, (0,1]
+//   cube point           vec3::random(-1,1): z,y,x (g++ order),  x,y,z, 2u-1 (vec3.h:119-121)
+//                        min+(max-min)*r  (vec3.h:124-131)
+//   near_zero / ruv eps  1e-8 / 1e-160                           1e-6f / 1e-8f (fp64: 1e-8 / 1e-160)
+//   pow(1-cos, 5)        std::pow                                powf, as the float chain ((x*x)*(x*x))*x
+//
+// plus two run-time switches that are independent of the policy:
+//   LoopForm  RECURSIVE (src/InOneWeekend/camera.h:137-156: att * ray_color(...))
+//             ITERATIVE (Global*/camera.h:84-127: running attenuation product, then * sky)
+//   SkyMode   SKY_CURRENT (serial camera.h:153: the ray that missed)
+//             SKY_PRIMARY (Global*/camera.h:121: the PRIMARY ray r, not curr_ray)
+//
+// The reference programs are the corners {Serial, RECURSIVE, SKY_CURRENT} -- pinned BYTE FOR
+// BYTE against the reference's own sources built into oracle/_ref -- and {Cuda, ITERATIVE,
+// SKY_PRIMARY}, the oracle of the HIP kernel.  Because the code is shared, the byte-exact pin
+// covers the material dispatch the hot path uses; the other corners exist so that tests can
+// walk from the pinned corner to the CUDA corner one switch at a time
+// (tests/test_oracle_pins.py: loop form with identical random numbers, then sky mode, then
+// policy against reference-run images with SURVEY A.5 noise floors).
 // =====================================================================================
-template <class T> struct Eps;
-template <> struct Eps<float> { static constexpr float near_zero = 1e-6f, ruv = 1e-8f; };    // vec3.h:50,124
-template <> struct Eps<double> { static constexpr double near_zero = 1e-8, ruv = 1e-160; };  // GlobalDouble vec3.h:50,125
+enum LoopForm { RECURSIVE = 0, ITERATIVE = 1 };
+enum SkyMode { SKY_CURRENT = 0, SKY_PRIMARY = 1 };
 
-template <class T> inline V3<T> dev_random_unit_vector(Xorwow& s) {  // vec3.h:117-127
-    for (;;) {
+struct SerialPolicy {
+    typedef double real;
+    typedef GlibcRand Rng;
+    static constexpr bool fused = false;
+    static constexpr double near_zero = 1e-8;                          // src/InOneWeekend/vec3.h:50
+    static constexpr double ruv_eps = 1e-160;                          // src/InOneWeekend/vec3.h:128
+    static double uniform(Rng& g) { return host_random<double>(g); }   // rtweekend.h:37-40
+    static V3<double> cube_point(Rng& g) {                             // vec3::random(-1,1): z,y,x (g++ order)
+        V3<double> p;
+        p.z = host_random<double>(g, -1.0, 1.0);
+        p.y = host_random<double>(g, -1.0, 1.0);
+        p.x = host_random<double>(g, -1.0, 1.0);
+        return p;
+    }
+    static double pow5(double x) { return std::pow(x, 5); }            // material.h:105
+};
+
+template <class T> struct CudaEps;
+template <> struct CudaEps<float> { static constexpr float near_zero = 1e-6f, ruv = 1e-8f; };    // vec3.h:50,124
+template <> struct CudaEps<double> { static constexpr double near_zero = 1e-8, ruv = 1e-160; };  // GlobalDouble vec3.h:50,125
+
+template <class T> struct CudaPolicy {
+    typedef T real;
+    typedef Xorwow Rng;
+    static constexpr bool fused = true;
+    static constexpr T near_zero = CudaEps<T>::near_zero;
+    static constexpr T ruv_eps = CudaEps<T>::ruv;
+    static T uniform(Rng& s) { return device_uniform<T>(s); }          // rtweekend.h:32-35
+    static V3<T> cube_point(Rng& s) {                                  // vec3.h:119-121: x, y, z
         T x = std::fma(device_uniform<T>(s), (T)2, (T)-1);
         T y = std::fma(device_uniform<T>(s), (T)2, (T)-1);
         T z = std::fma(device_uniform<T>(s), (T)2, (T)-1);
-        V3<T> p = {x, y, z};
-        T lensq = dot<true>(p, p);
-        if (Eps<T>::ruv < lensq && lensq <= (T)1) return vdiv(p, (T)std::sqrt(lensq));
+        return {x, y, z};
+    }
+    // material.h:65 powf(1 - cosine, 5) -- powf even in the double build (GlobalDouble material.h:68)
+    static T pow5(T x) { float f = (float)x; float f2 = f * f; return (T)((f2 * f2) * f); }
+};
+
+// vec3.h:117-127 (CUDA) / src/InOneWeekend/vec3.h:124-131
+template <class P> inline V3<typename P::real> random_unit_vector(typename P::Rng& rng) {
+    typedef typename P::real T;
+    for (;;) {
+        V3<T> p = P::cube_point(rng);
+        T lensq = len2<P::fused>(p);
+        if (P::ruv_eps < lensq && lensq <= (T)1) return vdiv(p, (T)std::sqrt(lensq));
     }
 }
 
+// material.h:62-66 (CUDA) / src/InOneWeekend/material.h:101-106:  r0 + (1-r0)*pow(1-cosine, 5)
+template <class P> inline typename P::real reflectance(typename P::real cosine, typename P::real ri) {
+    typedef typename P::real T;
+    T r0 = ((T)1 - ri) / ((T)1 + ri);
+    r0 = r0 * r0;
+    return mad<P::fused>((T)1 - r0, P::pow5((T)1 - cosine), r0);
+}
+
+// material.h:38-89 (CUDA) / src/InOneWeekend/material.h:32-92.  Returns false when the path is
+// absorbed (metal scattering below the surface).
+template <class P>
+inline bool scatter(const World<typename P::real>& w, V3<typename P::real> D, const Hit<typename P::real>& rec,
+                    typename P::Rng& rng, V3<typename P::real>& att, V3<typename P::real>& nd) {
+    typedef typename P::real T;
+    constexpr bool F = P::fused;
+    const int m = rec.idx;
+    if (w.type[m] == LAMBERTIAN) {                                    // material.h:38-49
+        nd = rec.normal + random_unit_vector<P>(rng);
+        if (std::fabs(nd.x) < P::near_zero && std::fabs(nd.y) < P::near_zero && std::fabs(nd.z) < P::near_zero) nd = rec.normal;
+        att = w.albedo[m];
+        return true;
+    }
+    if (w.type[m] == METAL) {                                         // material.h:51-59
+        V3<T> ur = unit<F>(reflect<F>(D, rec.normal));
+        nd = madd<F>(w.fuzz[m], random_unit_vector<P>(rng), ur);     // unit(reflected) + fuzz * random_unit_vector
+        att = w.albedo[m];
+        return dot<F>(nd, rec.normal) > 0;
+    }
+    att = {1, 1, 1};                                                  // material.h:68-89
+    T ri = rec.front ? ((T)1 / w.ri[m]) : w.ri[m];
+    V3<T> ud = unit<F>(D);
+    T cos_theta = std::fmin(dot<F>(-ud, rec.normal), (T)1);
+    T sin_theta = std::sqrt(mad<F>(-cos_theta, cos_theta, (T)1));    // sqrt(1 - cos*cos)
+    bool cannot = ri * sin_theta > (T)1;
+    if (cannot || reflectance<P>(cos_theta, ri) > P::uniform(rng)) nd = reflect<F>(ud, rec.normal);   // no draw on TIR
+    else nd = refract<F>(ud, rec.normal, ri);
+    return true;
+}
+
+// camera.h:121-123 (CUDA; `a` is double even in the float build) / src/InOneWeekend/camera.h:153-155:
+//   (1-a)*white + a*(0.5,0.7,1.0),  a = 0.5*(unit(dir).y + 1)
+template <class P> inline V3<typename P::real> sky_colour(V3<typename P::real> dir) {
+    typedef typename P::real T;
+    V3<T> ud = unit<P::fused>(dir);
+    double a = 0.5 * ((double)ud.y + 1.0);
+    T w1 = (T)(1.0 - a), w2 = (T)a;                                   // operator*(T, vec3): the weights are converted to T
+    return {mad<P::fused>(w2, (T)0.5, w1), mad<P::fused>(w2, (T)0.7, w1), mad<P::fused>(w2, (T)1.0, w1)};
+}
+
+struct RenderStats { uint64_t primary_rays, segments, sphere_tests, rng_draws; };
+
+// Global*/camera.h:78-128: iterative form.
+template <class P>
+inline V3<typename P::real> ray_color_iterative(V3<typename P::real> O0, V3<typename P::real> D0, int max_depth,
+                                                const World<typename P::real>& w, typename P::Rng& rng, SkyMode sky, RenderStats& st) {
+    typedef typename P::real T;
+    V3<T> O = O0, D = D0;                                             // camera.h:82
+    V3<T> atten = {1, 1, 1};                                          // :83
+    for (int depth = 0; depth < max_depth; ++depth) {                 // :84
+        Hit<T> rec;
+        ++st.segments; st.sphere_tests += (uint64_t)w.n;
+        if (hit_world<P::fused>(w, O, D, (T)0.001, std::numeric_limits<T>::infinity(), rec)) {   // :87
+            V3<T> att, nd;
+            if (!scatter<P>(w, D, rec, rng, att, nd)) return {0, 0, 0};   // :117
+            atten = atten * att;                                      // :112
+            O = rec.p; D = nd;                                        // :114
+        } else {
+            return atten * sky_colour<P>(sky == SKY_PRIMARY ? D0 : D);   // :120-124 (:121 uses the PRIMARY ray r)
+        }
+    }
+    return {0, 0, 0};                                                 // :127
+}
+
+// src/InOneWeekend/camera.h:137-156: recursive form.  D0 is only read by SKY_PRIMARY.
+template <class P>
+V3<typename P::real> ray_color_recursive(V3<typename P::real> O, V3<typename P::real> D, V3<typename P::real> D0, int depth,
+                                         const World<typename P::real>& w, typename P::Rng& rng, SkyMode sky, RenderStats& st) {
+    typedef typename P::real T;
+    if (depth <= 0) return {0, 0, 0};                                 // :139-140
+    Hit<T> rec;
+    ++st.segments; st.sphere_tests += (uint64_t)w.n;
+    if (hit_world<P::fused>(w, O, D, (T)0.001, std::numeric_limits<T>::infinity(), rec)) {   // :144
+        V3<T> att, nd;
+        if (scatter<P>(w, D, rec, rng, att, nd)) return att * ray_color_recursive<P>(rec.p, nd, D0, depth - 1, w, rng, sky, st);   // :147-149
+        return {0, 0, 0};                                             // :150
+    }
+    return sky_colour<P>(sky == SKY_PRIMARY ? D0 : D);                // :153-155
+}
+
+template <class P>
+inline V3<typename P::real> ray_color(LoopForm form, V3<typename P::real> O, V3<typename P::real> D, int max_depth,
+                                      const World<typename P::real>& w, typename P::Rng& rng, SkyMode sky, RenderStats& st) {
+    if (form == ITERATIVE) return ray_color_iterative<P>(O, D, max_depth, w, rng, sky, st);
+    return ray_color_recursive<P>(O, D, D, max_depth, w, rng, sky, st);
+}
+
+// =====================================================================================
+// CUDA-semantics render (camera.h:130-172): per-pixel XORWOW streams, so rows are independent
+// and are rendered by `threads` host threads (the result does not depend on the split).
+// =====================================================================================
 template <class T> inline V3<T> dev_random_in_unit_disk(Xorwow& s) {  // vec3.h:109-115; rtweekend.h:37-40
     for (;;) {
         T px = std::fma((T)2, device_uniform<T>(s), (T)-1);          // first argument drawn first (documented choice)
@@ -398,69 +563,10 @@ template <class T> inline V3<T> dev_random_in_unit_disk(Xorwow& s) {  // vec3.h:
     }
 }
 
-// material.h:62-66. powf even in the double build (GlobalDouble material.h:68).
-template <class T> inline T dev_reflectance(T cosine, T ri) {
-    T r0 = ((T)1 - ri) / ((T)1 + ri);
-    r0 = r0 * r0;
-    float x = (float)((T)1 - cosine);
-    float x2 = x * x;
-    float p5 = (x2 * x2) * x;
-    return std::fma((T)1 - r0, (T)p5, r0);
-}
-
-struct RenderStats { uint64_t primary_rays, segments, sphere_tests, rng_draws; };
-
 template <class T>
-inline V3<T> dev_ray_color(V3<T> O0, V3<T> D0, int max_depth, const World<T>& w, Xorwow& s, RenderStats& st) {
-    V3<T> O = O0, D = D0;                                             // camera.h:82
-    V3<T> atten = {1, 1, 1};                                          // :83
-    for (int depth = 0; depth < max_depth; ++depth) {                 // :84
-        Hit<T> rec;
-        ++st.segments; st.sphere_tests += (uint64_t)w.n;
-        if (hit_world<true>(w, O, D, (T)0.001, std::numeric_limits<T>::infinity(), rec)) {   // :87
-            V3<T> nd, att; bool ok;
-            const int m = rec.idx;
-            if (w.type[m] == LAMBERTIAN) {                            // material.h:38-49
-                nd = rec.normal + dev_random_unit_vector<T>(s);
-                if (std::fabs(nd.x) < Eps<T>::near_zero && std::fabs(nd.y) < Eps<T>::near_zero &&
-                    std::fabs(nd.z) < Eps<T>::near_zero) nd = rec.normal;
-                att = w.albedo[m]; ok = true;
-            } else if (w.type[m] == METAL) {                          // material.h:51-59
-                V3<T> refl = reflect<true>(D, rec.normal);
-                V3<T> ur = unit<true>(refl);
-                V3<T> ruv = dev_random_unit_vector<T>(s);
-                nd = madd<true>(w.fuzz[m], ruv, ur);
-                att = w.albedo[m];
-                ok = dot<true>(nd, rec.normal) > 0;
-            } else {                                                  // material.h:68-89
-                att = {1, 1, 1};
-                T eta = w.ri[m];
-                T ri = rec.front ? ((T)1 / eta) : eta;
-                V3<T> ud = unit<true>(D);
-                T cos_theta = std::fmin(dot<true>(-ud, rec.normal), (T)1);
-                T sin_theta = std::sqrt(std::fma(-cos_theta, cos_theta, (T)1));
-                bool cannot = ri * sin_theta > (T)1;
-                if (cannot || dev_reflectance<T>(cos_theta, ri) > device_uniform<T>(s)) nd = reflect<true>(ud, rec.normal);
-                else nd = refract<true>(ud, rec.normal, ri);
-                ok = true;
-            }
-            if (!ok) return {0, 0, 0};                                // camera.h:117
-            atten = atten * att;                                      // :112
-            O = rec.p; D = nd;                                        // :114
-        } else {
-            V3<T> ud = unit<true>(D0);                                // :121 -- PRIMARY ray r, not curr_ray
-            double a = 0.5 * ((double)ud.y + 1.0);                    // :122 (double even in the float build)
-            T w1 = (T)(1.0 - a), w2 = (T)a;                           // :123 operator*(T, vec3)
-            V3<T> sky = {std::fma(w2, (T)0.5, w1), std::fma(w2, (T)0.7, w1), std::fma(w2, (T)1.0, w1)};
-            return atten * sky;
-        }
-    }
-    return {0, 0, 0};                                                 // :127
-}
-
-template <class T>
-void render_cuda_semantics(const World<T>& w, const Camera<T>& cam, uint64_t seed, int row0, int row1,
-                           T* out_rgb /* (row1-row0)*W*3 */, RenderStats& st, uint32_t* seg_per_pixel = nullptr) {
+void render_cuda_rows(const World<T>& w, const Camera<T>& cam, uint64_t seed, int row0, int row1, int out_row0,
+                      T* out_rgb, RenderStats& st, uint32_t* seg_per_pixel, LoopForm form, SkyMode sky) {
+    typedef CudaPolicy<T> P;
     for (int j = row0; j < row1; ++j)
         for (int i = 0; i < cam.W; ++i) {
             const int pixel_index = j * cam.W + i;                    // camera.h:134
@@ -479,32 +585,51 @@ void render_cuda_semantics(const World<T>& w, const Camera<T>& cam, uint64_t see
                 }
                 V3<T> dir = ps - org;                                 // :154
                 ++st.primary_rays;
-                pc = pc + dev_ray_color<T>(org, dir, cam.B, w, s, st); // :160
+                pc = pc + ray_color<P>(form, org, dir, cam.B, w, s, sky, st);   // :160
             }
-            if (seg_per_pixel) seg_per_pixel[(size_t)(j - row0) * cam.W + i] = (uint32_t)(st.segments - seg0);
+            const size_t o_idx = (size_t)(j - out_row0) * cam.W + i;
+            if (seg_per_pixel) seg_per_pixel[o_idx] = (uint32_t)(st.segments - seg0);
             pc = scale(cam.pixel_samples_scale, pc);                  // :167
-            T* o = out_rgb + ((size_t)(j - row0) * cam.W + i) * 3;
+            T* o = out_rgb + o_idx * 3;
             o[0] = pc.x > 0 ? (T)std::sqrt(pc.x) : 0;                 // color.h:10-13
             o[1] = pc.y > 0 ? (T)std::sqrt(pc.y) : 0;
             o[2] = pc.z > 0 ? (T)std::sqrt(pc.z) : 0;
         }
 }
 
+int g_threads = 0;   // 0: std::thread::hardware_concurrency(), capped at 16 (oracle_set_threads)
+
+template <class T>
+void render_cuda_semantics(const World<T>& w, const Camera<T>& cam, uint64_t seed, int row0, int row1,
+                           T* out_rgb /* (row1-row0)*W*3 */, RenderStats& st, uint32_t* seg_per_pixel = nullptr,
+                           LoopForm form = ITERATIVE, SkyMode sky = SKY_PRIMARY) {
+    jump_tables();                                                    // build once, before the threads read it
+    int nt = g_threads > 0 ? g_threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    const int rows = row1 - row0;
+    if ((long long)rows * cam.W * cam.S < 20000) nt = 1;
+    if (nt > rows) nt = rows > 0 ? rows : 1;
+    if (nt <= 1) { render_cuda_rows<T>(w, cam, seed, row0, row1, row0, out_rgb, st, seg_per_pixel, form, sky); return; }
+    // rows are dealt in small interleaved chunks so that sky rows and ground rows mix per thread
+    std::vector<RenderStats> part((size_t)nt, RenderStats{0, 0, 0, 0});
+    std::vector<std::thread> pool;
+    std::atomic<int> next(row0);
+    for (int t = 0; t < nt; ++t)
+        pool.emplace_back([&, t]() {
+            for (;;) {
+                const int r = next.fetch_add(2);
+                if (r >= row1) break;
+                render_cuda_rows<T>(w, cam, seed, r, std::min(r + 2, row1), row0, out_rgb, part[(size_t)t], seg_per_pixel, form, sky);
+            }
+        });
+    for (std::thread& th : pool) th.join();
+    for (const RenderStats& p : part) { st.primary_rays += p.primary_rays; st.segments += p.segments; st.sphere_tests += p.sphere_tests; }
+}
+
 // =====================================================================================
-// Serial semantics (src/InOneWeekend): fp64, one rand() stream, recursion, sky from current ray.
+// Serial-semantics render (src/InOneWeekend/camera.h:34-54, 105-135): fp64, ONE rand() stream
+// shared by scene generation and rendering, pixels in row-major order.
 // =====================================================================================
 typedef V3<double> D3;
-
-inline D3 ser_random_unit_vector(GlibcRand& g) {                      // vec3.h:124-131 (serial)
-    for (;;) {
-        D3 p;                                                         // vec3::random(-1,1): z,y,x (g++ order)
-        p.z = host_random<double>(g, -1.0, 1.0);
-        p.y = host_random<double>(g, -1.0, 1.0);
-        p.x = host_random<double>(g, -1.0, 1.0);
-        double lensq = len2<false>(p);
-        if (1e-160 < lensq && lensq <= 1.0) return vdiv(p, std::sqrt(lensq));
-    }
-}
 
 inline D3 ser_random_in_unit_disk(GlibcRand& g) {                     // vec3.h:116-122 (serial)
     for (;;) {
@@ -515,55 +640,16 @@ inline D3 ser_random_in_unit_disk(GlibcRand& g) {                     // vec3.h:
     }
 }
 
-inline double ser_reflectance(double cosine, double ri) {             // material.h:101-106 (serial)
-    double r0 = (1 - ri) / (1 + ri);
-    r0 = r0 * r0;
-    return r0 + (1 - r0) * std::pow((1 - cosine), 5);
-}
-
-D3 ser_ray_color(D3 O, D3 D, int depth, const World<double>& w, GlibcRand& g, RenderStats& st) {   // camera.h:137-156
-    if (depth <= 0) return {0, 0, 0};
-    Hit<double> rec;
-    ++st.segments; st.sphere_tests += (uint64_t)w.n;
-    if (hit_world<false>(w, O, D, 0.001, std::numeric_limits<double>::infinity(), rec)) {
-        const int m = rec.idx;
-        D3 nd, att;
-        if (w.type[m] == LAMBERTIAN) {                                // material.h:32-43
-            nd = rec.normal + ser_random_unit_vector(g);
-            if (std::fabs(nd.x) < 1e-8 && std::fabs(nd.y) < 1e-8 && std::fabs(nd.z) < 1e-8) nd = rec.normal;
-            att = w.albedo[m];
-        } else if (w.type[m] == METAL) {                              // material.h:50-58
-            D3 refl = reflect<false>(D, rec.normal);
-            D3 ur = unit<false>(refl);
-            nd = ur + scale(w.fuzz[m], ser_random_unit_vector(g));
-            att = w.albedo[m];
-            if (!(dot<false>(nd, rec.normal) > 0)) return {0, 0, 0};
-        } else {                                                      // material.h:70-92
-            att = {1, 1, 1};
-            double ri = rec.front ? (1.0 / w.ri[m]) : w.ri[m];
-            D3 ud = unit<false>(D);
-            double cos_theta = std::fmin(dot<false>(-ud, rec.normal), 1.0);
-            double sin_theta = std::sqrt(1.0 - cos_theta * cos_theta);
-            bool cannot = ri * sin_theta > 1.0;
-            if (cannot || ser_reflectance(cos_theta, ri) > host_random<double>(g)) nd = reflect<false>(ud, rec.normal);
-            else nd = refract<false>(ud, rec.normal, ri);
-        }
-        return att * ser_ray_color(rec.p, nd, depth - 1, w, g, st);   // camera.h:149
-    }
-    D3 ud = unit<false>(D);                                           // camera.h:153 -- CURRENT ray
-    double a = 0.5 * (ud.y + 1.0);
-    return scale(1.0 - a, D3{1.0, 1.0, 1.0}) + scale(a, D3{0.5, 0.7, 1.0});
-}
-
 inline int to_byte(double c) {                                        // color.h:29-47 (serial), main.cu:374-376
     double g = c > 0 ? std::sqrt(c) : 0;
     double cl = g < 0.000 ? 0.000 : (g > 0.999 ? 0.999 : g);
     return (int)(256 * cl);
 }
 
-// Renders rows [row0,row1) with stride `row_step`... the single rand() stream makes a row
-// subset a different (equally valid) sample, so the byte-exact pin always renders all rows.
-void render_serial_semantics(int scene_id, int W, int H, int S, int depth, std::string& p3, RenderStats& st) {
+// The single rand() stream makes a row subset a different (equally valid) sample, so the
+// byte-exact pin always renders all rows.  form/sky default to the reference's program.
+void render_serial_semantics(int scene_id, int W, int H, int S, int depth, std::string& p3, RenderStats& st,
+                             LoopForm form = RECURSIVE, SkyMode sky = SKY_CURRENT) {
     GlibcRand g(1);
     Scene<double> sc; build_scene<double>(scene_id, sc, g);
     World<double> w; compact(sc, w);
@@ -584,7 +670,7 @@ void render_serial_semantics(int scene_id, int W, int H, int S, int depth, std::
                     org = cam.center + scale(p.x, cam.defocus_disk_u) + scale(p.y, cam.defocus_disk_v);
                 }
                 ++st.primary_rays;
-                pc = pc + ser_ray_color(org, ps - org, depth, w, g, st);
+                pc = pc + ray_color<SerialPolicy>(form, org, ps - org, depth, w, g, sky, st);
             }
             pc = scale(cam.pixel_samples_scale, pc);
             std::snprintf(buf, sizeof buf, "%d %d %d\n", to_byte(pc.x), to_byte(pc.y), to_byte(pc.z));
@@ -679,43 +765,70 @@ double oracle_uniform_f64(unsigned int* state6) {
     return r;
 }
 
-// CUDA-semantics render of rows [row0,row1) of a compact world given as arrays.
-// stats4 = {primary_rays, segments, sphere_tests, 0}.
-int oracle_render(int precision, int n, const void* center_radius, const void* albedo_fuzz, const void* ri, const int* type,
-                  const int* cam_ints4, const void* cam_flat20, unsigned long long seed, int row0, int row1,
-                  void* out_rgb, unsigned long long* stats4) {
+// Host threads used by the CUDA-semantics renders (0 = all cores, at most 16).  The result does
+// not depend on it (per-pixel streams).
+void oracle_set_threads(int n) { g_threads = n < 0 ? 0 : n; }
+
+// CUDA-policy render of rows [row0,row1) of a compact world given as arrays, with the loop form
+// (0 recursive, 1 iterative) and sky mode (0 current ray, 1 primary ray) switches.  The
+// reference's GPU program is (1, 1).   stats4 = {primary_rays, segments, sphere_tests, 0}.
+int oracle_render_modes(int precision, int n, const void* center_radius, const void* albedo_fuzz, const void* ri, const int* type,
+                        const int* cam_ints4, const void* cam_flat20, unsigned long long seed, int row0, int row1,
+                        int loop_form, int sky_mode, void* out_rgb, unsigned long long* stats4, unsigned int* seg_per_pixel) {
     RenderStats st = {0, 0, 0, 0};
+    const LoopForm form = loop_form ? ITERATIVE : RECURSIVE;
+    const SkyMode sky = sky_mode ? SKY_PRIMARY : SKY_CURRENT;
     if (precision == 32) {
         World<float> w; world_from_arrays(n, (const float*)center_radius, (const float*)albedo_fuzz, (const float*)ri, type, w);
         Camera<float> c; camera_from_flat(c, cam_ints4, (const float*)cam_flat20);
-        render_cuda_semantics<float>(w, c, seed, row0, row1, (float*)out_rgb, st);
+        render_cuda_semantics<float>(w, c, seed, row0, row1, (float*)out_rgb, st, seg_per_pixel, form, sky);
     } else if (precision == 64) {
         World<double> w; world_from_arrays(n, (const double*)center_radius, (const double*)albedo_fuzz, (const double*)ri, type, w);
         Camera<double> c; camera_from_flat(c, cam_ints4, (const double*)cam_flat20);
-        render_cuda_semantics<double>(w, c, seed, row0, row1, (double*)out_rgb, st);
+        render_cuda_semantics<double>(w, c, seed, row0, row1, (double*)out_rgb, st, seg_per_pixel, form, sky);
     } else return -1;
     if (stats4) { stats4[0] = st.primary_rays; stats4[1] = st.segments; stats4[2] = st.sphere_tests; stats4[3] = 0; }
     return 0;
+}
+
+// The reference's GPU program: CUDA policy, iterative loop, sky from the primary ray.
+int oracle_render(int precision, int n, const void* center_radius, const void* albedo_fuzz, const void* ri, const int* type,
+                  const int* cam_ints4, const void* cam_flat20, unsigned long long seed, int row0, int row1,
+                  void* out_rgb, unsigned long long* stats4) {
+    return oracle_render_modes(precision, n, center_radius, albedo_fuzz, ri, type, cam_ints4, cam_flat20, seed, row0, row1, 1, 1, out_rgb, stats4, nullptr);
 }
 
 // As oracle_render (fp32) plus the number of path segments (hit_world calls) of every pixel.
 int oracle_render_segments_f32(int n, const float* center_radius, const float* albedo_fuzz, const float* ri, const int* type,
                                const int* cam_ints4, const float* cam_flat20, unsigned long long seed, int row0, int row1,
                                float* out_rgb, unsigned int* seg_per_pixel) {
-    RenderStats st = {0, 0, 0, 0};
-    World<float> w; world_from_arrays(n, center_radius, albedo_fuzz, ri, type, w);
-    Camera<float> c; camera_from_flat(c, cam_ints4, cam_flat20);
-    render_cuda_semantics<float>(w, c, seed, row0, row1, out_rgb, st, seg_per_pixel);
-    return 0;
+    return oracle_render_modes(32, n, center_radius, albedo_fuzz, ri, type, cam_ints4, cam_flat20, seed, row0, row1, 1, 1, out_rgb, nullptr, seg_per_pixel);
 }
 
-// Serial-semantics render; returns the P3 text length, copies up to cap bytes.
-long long oracle_render_serial(int scene_id, int W, int H, int S, int depth, char* out, long long cap, unsigned long long* stats4) {
+// Serial-policy render (one rand() stream, all rows) with the same two switches; the reference's
+// serial program is (0, 0).  Returns the P3 text length, copies up to cap bytes.
+long long oracle_render_serial_modes(int scene_id, int W, int H, int S, int depth, int loop_form, int sky_mode,
+                                     char* out, long long cap, unsigned long long* stats4) {
     std::string p3; RenderStats st = {0, 0, 0, 0};
-    render_serial_semantics(scene_id, W, H, S, depth, p3, st);
+    render_serial_semantics(scene_id, W, H, S, depth, p3, st, loop_form ? ITERATIVE : RECURSIVE, sky_mode ? SKY_PRIMARY : SKY_CURRENT);
     if (out && cap > 0) std::memcpy(out, p3.data(), (size_t)std::min<long long>(cap, (long long)p3.size()));
     if (stats4) { stats4[0] = st.primary_rays; stats4[1] = st.segments; stats4[2] = st.sphere_tests; stats4[3] = 0; }
     return (long long)p3.size();
+}
+long long oracle_render_serial(int scene_id, int W, int H, int S, int depth, char* out, long long cap, unsigned long long* stats4) {
+    return oracle_render_serial_modes(scene_id, W, H, S, depth, 0, 0, out, cap, stats4);
+}
+
+// The sky term alone (camera.h:121-123 / serial camera.h:153-155) for one direction.
+// policy: 0 serial (fp64, unfused), 32 / 64 CUDA policy in that precision.  out3 is double.
+int oracle_sky(int policy, const double* dir3, double* out3) {
+    if (policy == 0) { D3 c = sky_colour<SerialPolicy>({dir3[0], dir3[1], dir3[2]}); out3[0] = c.x; out3[1] = c.y; out3[2] = c.z; return 0; }
+    if (policy == 64) { D3 c = sky_colour<CudaPolicy<double>>({dir3[0], dir3[1], dir3[2]}); out3[0] = c.x; out3[1] = c.y; out3[2] = c.z; return 0; }
+    if (policy == 32) {
+        V3<float> c = sky_colour<CudaPolicy<float>>({(float)dir3[0], (float)dir3[1], (float)dir3[2]});
+        out3[0] = c.x; out3[1] = c.y; out3[2] = c.z; return 0;
+    }
+    return -1;
 }
 
 // Single-primitive probes used by the analytic known-answer tests (tests/test_oracle_kat.py).
@@ -729,6 +842,6 @@ int oracle_hit_sphere_f64(const double* center, double radius, const double* O, 
 }
 void oracle_reflect_f64(const double* v, const double* n, double* out) { D3 r = reflect<true, double>({v[0], v[1], v[2]}, {n[0], n[1], n[2]}); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
 void oracle_refract_f64(const double* v, const double* n, double eta, double* out) { D3 r = refract<true, double>({v[0], v[1], v[2]}, {n[0], n[1], n[2]}, eta); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
-double oracle_reflectance_f64(double cosine, double ri) { return dev_reflectance<double>(cosine, ri); }
+double oracle_reflectance_f64(double cosine, double ri) { return reflectance<CudaPolicy<double>>(cosine, ri); }
 
 }  // extern "C"

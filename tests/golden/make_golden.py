@@ -14,6 +14,13 @@ What each fixture is and where it comes from:
                            SURVEY.md Appendix A.3, dumped there from the reference's structs).
   cuda_sem_*.npy           small CUDA-semantics renders from the oracle (regression + the
                            golden the -m gpu tests compare the HIP path with).
+  ref_serial_320x192_100spp_50b.npz
+                           the images (uint8 levels of the P3 text) the REFERENCE's serial tracer
+                           (oracle/_ref/ref_serial_driver) prints for scenes 1/2/3 at 320x192, 100 spp,
+                           depth 50, + ref_serial_320x192_100spp_50b.json: md5 of each P3 text and the
+                           ppm_diff noise floor of each scene (two oracle renders that differ only
+                           in the RNG seed; SURVEY.md A.5 lists the same floors for scenes 1 and 3).
+                           Used by the sky-mode / policy pins of the CUDA-semantics oracle.
 No reference source text is stored here: only inputs (flags) and outputs (hashes, arrays).
 """
 import hashlib
@@ -57,12 +64,32 @@ def main():
                                        "md5": hashlib.md5(out).hexdigest(), "bytes": len(out)}
     json.dump(serial, open(path, "w"), indent=1)
 
+    from tests.oracle_lib import p3_levels, to_levels, diff_stats, SKY_CURRENT
+    orc = Oracle()
+    import raytracingincuda_amd as rt
+    imgs, meta = {}, {"config": {"width": 320, "height": 192, "samples": 100, "depth": 50}, "scenes": {}}
+    for sid in (1, 2, 3):
+        out = subprocess.run([drv, str(sid), "320", "192", "100", "50"], capture_output=True, check=True).stdout
+        imgs["s%d" % sid] = p3_levels(out)
+        sc = orc.build_scene(sid, 64)
+        keep = sc["valid"] != 0
+        comp = {k: (v[keep] if isinstance(v, np.ndarray) else v) for k, v in sc.items()}
+        cam = rt.camera(64, 320, 192, 100, 50)
+        a, _ = orc.render(64, comp, cam, 1227, sky_mode=SKY_CURRENT)
+        b, _ = orc.render(64, comp, cam, 99, sky_mode=SKY_CURRENT)
+        floor = diff_stats(to_levels(a), to_levels(b))
+        fb = diff_stats(to_levels(a)[..., 2], to_levels(b)[..., 2])
+        meta["scenes"][str(sid)] = {"md5": hashlib.md5(out).hexdigest(), "bytes": len(out),
+                                    "floor_mean": floor["mean"], "floor_p99": floor["p99"], "floor_max": floor["max"],
+                                    "floor_mean_blue": fb["mean"], "floor_p99_blue": fb["p99"]}
+    np.savez_compressed(os.path.join(HERE, "ref_serial_320x192_100spp_50b.npz"), **imgs)
+    json.dump(meta, open(os.path.join(HERE, "ref_serial_320x192_100spp_50b.json"), "w"), indent=1)
+
     kat_exe = "/tmp/rtiow_make_xorwow_kat"
     subprocess.run(["hipcc", "-O1", "-o", kat_exe, os.path.join(HERE, "make_xorwow_kat.cpp")], check=True)
     kat = subprocess.run([kat_exe], capture_output=True, check=True).stdout
     open(os.path.join(HERE, "xorwow_rocrand_kat.json"), "wb").write(kat)
 
-    orc = Oracle()
     tables = {}
     for prec in (32, 64):
         for sid in (1, 2, 3):
@@ -71,7 +98,6 @@ def main():
                 tables["s%d_f%d_%s" % (sid, prec, k)] = sc[k]
     np.savez_compressed(os.path.join(HERE, "scene_tables.npz"), **tables)
 
-    import raytracingincuda_amd as rt
     for name, prec, sid, W, H, S, B in CUDA_SEM_CONFIGS:
         sc = orc.build_scene(sid, prec)
         keep = sc["valid"] != 0

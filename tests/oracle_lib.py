@@ -17,6 +17,30 @@ def ensure_built():
     return ORACLE_SO
 
 
+RECURSIVE, ITERATIVE = 0, 1        # loop form (oracle/rtiow_oracle.cpp LoopForm)
+SKY_CURRENT, SKY_PRIMARY = 0, 1    # sky mode
+
+
+def p3_levels(p3):
+    """P3 text -> uint8 [H, W, 3]."""
+    tok = p3.split()
+    W, H = int(tok[1]), int(tok[2])
+    return np.array(tok[4:], np.int32).reshape(H, W, 3).astype(np.uint8)
+
+
+def to_levels(img):
+    """float image -> the P3 writer's levels int(256*clamp(c, 0, 0.999)) (main.cu:374-376)."""
+    return np.floor(256.0 * np.clip(np.asarray(img, np.float64), 0.0, 0.999)).astype(np.uint8)
+
+
+def diff_stats(a, b):
+    """ppm_diff statistics between two uint8 images: mean |d|, p99, max, per-channel bias."""
+    d = a.astype(np.int32) - b.astype(np.int32)
+    ad = np.abs(d)
+    return {"mean": float(ad.mean()), "p99": float(np.percentile(ad, 99)), "max": int(ad.max()),
+            "bias": [float(d[..., c].mean()) for c in range(3)]}
+
+
 def _dt(prec):
     return np.float32 if prec == 32 else np.float64
 
@@ -37,8 +61,14 @@ class Oracle:
         L.oracle_uniform_f64.argtypes = [vp]
         L.oracle_uniform_f64.restype = ctypes.c_double
         L.oracle_render.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp, u64, ctypes.c_int, ctypes.c_int, vp, vp]
+        L.oracle_render_modes.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp, u64, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, vp, vp, vp]
         L.oracle_render_serial.argtypes = [ctypes.c_int] * 5 + [vp, ctypes.c_longlong, vp]
         L.oracle_render_serial.restype = ctypes.c_longlong
+        L.oracle_render_serial_modes.argtypes = [ctypes.c_int] * 7 + [vp, ctypes.c_longlong, vp]
+        L.oracle_render_serial_modes.restype = ctypes.c_longlong
+        L.oracle_sky.argtypes = [ctypes.c_int, vp, vp]
+        L.oracle_set_threads.argtypes = [ctypes.c_int]
         L.oracle_hit_sphere_f64.argtypes = [vp, ctypes.c_double, vp, vp, ctypes.c_double, ctypes.c_double, vp, vp, vp, vp]
         L.oracle_reflect_f64.argtypes = [vp, vp, vp]
         L.oracle_refract_f64.argtypes = [vp, vp, ctypes.c_double, vp]
@@ -95,8 +125,10 @@ class Oracle:
                          cam.defocus_angle, *cam.defocus_disk_u, *cam.defocus_disk_v], dt)
         return ints, flat
 
-    def render(self, prec, scene, cam, seed=1227, row0=0, row1=None):
-        """CUDA-semantics render of a COMPACT scene (all slots valid). cam: api.CameraF32/F64."""
+    def render(self, prec, scene, cam, seed=1227, row0=0, row1=None, loop_form=ITERATIVE, sky_mode=SKY_PRIMARY, segments=False):
+        """CUDA-policy render of a COMPACT scene (all slots valid). cam: api.CameraF32/F64.
+        The defaults are the reference's GPU program (iterative loop, sky from the primary ray);
+        the two switches exist for the pins in tests/test_oracle_pins.py."""
         dt = _dt(prec)
         ints, flat = self.camera_to_flat(cam, prec)
         W, H = int(ints[0]), int(ints[1])
@@ -105,14 +137,28 @@ class Oracle:
         ri = np.ascontiguousarray(scene["refraction_index"], dt); ty = np.ascontiguousarray(scene["type"], np.int32)
         out = np.zeros((row1 - row0, W, 3), dt)
         stats = np.zeros(4, np.uint64)
-        rc = self.L.oracle_render(prec, len(ty), cr.ctypes.data, af.ctypes.data, ri.ctypes.data, ty.ctypes.data,
-                                  ints.ctypes.data, flat.ctypes.data, seed, row0, row1, out.ctypes.data, stats.ctypes.data)
+        seg = np.zeros((row1 - row0, W), np.uint32) if segments else None
+        rc = self.L.oracle_render_modes(prec, len(ty), cr.ctypes.data, af.ctypes.data, ri.ctypes.data, ty.ctypes.data,
+                                        ints.ctypes.data, flat.ctypes.data, seed, row0, row1, loop_form, sky_mode,
+                                        out.ctypes.data, stats.ctypes.data, seg.ctypes.data if segments else None)
         assert rc == 0
+        if segments:
+            return out, [int(x) for x in stats], seg
         return out, [int(x) for x in stats]
 
-    def render_serial(self, scene_id, W, H, S, depth):
+    def render_serial(self, scene_id, W, H, S, depth, loop_form=RECURSIVE, sky_mode=SKY_CURRENT):
+        """Serial-policy render (P3 text).  The defaults are the reference's serial program."""
         cap = W * H * 12 + 64
         buf = ctypes.create_string_buffer(cap)
         stats = np.zeros(4, np.uint64)
-        n = self.L.oracle_render_serial(scene_id, W, H, S, depth, buf, cap, stats.ctypes.data)
+        n = self.L.oracle_render_serial_modes(scene_id, W, H, S, depth, loop_form, sky_mode, buf, cap, stats.ctypes.data)
         return buf.raw[:n], [int(x) for x in stats]
+
+    def sky(self, policy, direction):
+        """Sky term alone: policy 0 = serial (fp64), 32 / 64 = CUDA policy in that precision."""
+        d = np.ascontiguousarray(direction, np.float64); out = np.zeros(3)
+        assert self.L.oracle_sky(policy, d.ctypes.data, out.ctypes.data) == 0
+        return out
+
+    def set_threads(self, n):
+        self.L.oracle_set_threads(n)

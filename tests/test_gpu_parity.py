@@ -45,6 +45,13 @@ def _oracle(oracle, rt, prec, scene_id, W, H, S, B, seed=1227, rows=None):
     return oracle.render(prec, sc, cam, seed, rows[0], rows[1])
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def _same_bits(a, b):
     return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
 
@@ -358,6 +365,58 @@ def test_baseline_config3_1280x720(rt, oracle):
     assert _same_bits(full, a)
 
 
+def test_scene1_at_config3_and_config4_geometry_vs_oracle(rt, oracle):
+    """"additionally run C3/C4 geometry on scene 1" (487 spheres, the only scene
+    the reference published numbers for): oracle rows at 1280x720 and 1920x1080, 100 spp, 50 bounces."""
+    for W, H, rows in ((1280, 720, (3, 377, 719)), (1920, 1080, (540, 1001))):
+        a = _render(rt, 32, 1, W, H, 100, 50, threads=0)
+        assert np.isfinite(a).all() and a.min() >= 0 and a.max() <= 1.0 + 1e-6
+        for row in rows:
+            want, _ = _oracle(oracle, rt, 32, 1, W, H, 100, 50, rows=(row, row + 1))
+            assert _same_bits(a[row:row + 1], want), (W, H, row)
+
+
+def _render_scene(rt, prec, scene, cam, sched=2, seed=1227):
+    with rt.Renderer(0, prec) as r:
+        r.set_camera(cam); r.set_scene(scene); r.set_schedule(sched); r.init_rng(seed)
+        r.render(0)
+        segs = r.count_segments(0)
+        return r.read_framebuffer(), segs
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+def test_sky_comes_from_the_primary_ray_known_answer_on_the_gpu(rt, oracle, prec):
+    """camera.h:121 on the HIP path itself, with NO oracle in the comparison: in front of a perfect
+    mirror every path is hit -> reflect -> miss with attenuation exactly 1, and the CUDA program
+    shades the miss with the PRIMARY ray, so at 1 sample per pixel the mirror image must be
+    bit-identical to the image of the empty scene (see tests/test_oracle_pins.py for the CPU twin,
+    which also checks that sky-from-the-current-ray gives a different picture).  Then the analytic
+    gradient and, last, the oracle."""
+    from tests.test_oracle_pins import probe_scene
+    W, H = 64, 40
+    cam = rt.camera(prec, W, H, 1, 10)
+    for sched in (rt.SCHED_SORTED, rt.SCHED_STATIC):
+        empty, seg_e = _render_scene(rt, prec, probe_scene(prec, "empty"), cam, sched)
+        mirror, seg_m = _render_scene(rt, prec, probe_scene(prec, "mirror"), cam, sched)
+        assert seg_e == W * H and seg_m == 2 * W * H
+        assert _same_bits(empty, mirror), sched
+    p00, du, dv, c = (np.array(list(x), np.float64) for x in (cam.pixel00_loc, cam.pixel_delta_u, cam.pixel_delta_v, cam.center))
+    jj, ii = np.mgrid[0:H, 0:W]
+    d = p00 + ii[..., None] * du + jj[..., None] * dv - c
+    a = 0.5 * (d[..., 1] / np.linalg.norm(d, axis=-1) + 1.0)
+    want = (1.0 - a)[..., None] * np.ones(3) + a[..., None] * np.array([0.5, 0.7, 1.0])
+    slack = 0.25 * (np.linalg.norm(dv) + np.linalg.norm(du) + 0.06) / 10.0
+    assert np.abs(empty.astype(np.float64) ** 2 - want).max() <= slack
+    ref, _ = oracle.render(prec, probe_scene(prec, "mirror"), cam, 1227)
+    assert _same_bits(mirror, ref)
+    # many samples: later samples start from different RNG states in the two scenes (the metal
+    # scatter draws a random_unit_vector even at fuzz 0, material.h:56), so only statistics agree
+    cam16 = rt.camera(prec, W, H, 16, 10)
+    e16, _ = _render_scene(rt, prec, probe_scene(prec, "empty"), cam16)
+    m16, _ = _render_scene(rt, prec, probe_scene(prec, "mirror"), cam16)
+    assert not _same_bits(e16, m16) and np.abs(e16.astype(np.float64) - m16).max() < 2e-3
+
+
 def test_baseline_config5_fp64_500spp_and_float_vs_double(rt, oracle, tmp_path):
     """BASELINE configs[4]: fp64, scene 3, 1920x1080, 500 spp, 50 bounces.  Oracle row spot check,
     and the reference's own acceptance procedure (README.md:101-116): ppm_diff of the float and the
@@ -441,7 +500,7 @@ def test_bench_two_rank_rehearsal(rt):
     from tests.conftest import ROOT
     env = dict(os.environ, RTIOW_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--width", "256", "--height", "144", "--samples", "64", "--bounces", "10"],
                        capture_output=True, text=True, cwd=ROOT, env=env, timeout=240)
     assert r.returncode == 0, r.stderr[-2000:]

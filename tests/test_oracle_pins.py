@@ -229,21 +229,218 @@ def test_cuda_semantics_golden_images_regress(oracle, golden_dir, native):
         assert stats[0] == W * H * S and stats[1] >= stats[0]
 
 
-def test_cuda_semantics_row_ranges_and_statistics(oracle, native):
+def test_cuda_semantics_row_ranges_and_thread_independence(oracle, native):
     """Row subsets equal the same rows of the full render (streams are keyed by the global
-    pixel index), and the CUDA-semantics image is statistically the serial image apart from
-    the documented sky-term delta (primary-ray sky is whiter; SURVEY §0 finding 2)."""
+    pixel index), whatever the number of host threads the oracle uses."""
     from tests.conftest import compact
     sc = compact(oracle.build_scene(3, 32))
     cam = native.camera(32, 96, 56, 8, 20)
-    full, _ = oracle.render(32, sc, cam, 1227)
+    full, st = oracle.render(32, sc, cam, 1227)
     part, _ = oracle.render(32, sc, cam, 1227, 16, 40)
     assert np.array_equal(full[16:40], part)
     assert np.isfinite(full).all() and full.min() >= 0 and full.max() <= 1.0 + 1e-6
-    p3, _ = oracle.render_serial(3, 96, 56, 8, 20)
-    ser = np.array(p3.split()[4:], np.float64).reshape(56, 96, 3)
-    cud = np.floor(256 * np.clip(full.astype(np.float64), 0, 0.999))
-    # sky rows (top of the image) are pure sky in both semantics: same blue gradient
-    assert abs(ser[:4].mean() - cud[:4].mean()) < 3.0
-    # whole-image means agree to a few levels (noise 8 spp + the sky-term delta)
-    assert abs(ser.mean() - cud.mean()) < 12.0
+    oracle.set_threads(1)
+    try:
+        one, st1, seg = oracle.render(32, sc, cam, 1227, segments=True)
+    finally:
+        oracle.set_threads(0)
+    assert np.array_equal(full.view(np.uint8), one.view(np.uint8)) and st == st1
+    assert int(seg.sum()) == st1[1]
+
+
+# ---------------------------------------------------------------------------------------
+# Pins of the CUDA-semantics corner of the oracle -- the one the HIP kernel is compared with.
+#
+# oracle/rtiow_oracle.cpp has ONE scatter / sky / ray_color implementation, parameterised by a
+# policy (serial: fp64, rand(), unfused | CUDA: T, XORWOW, explicit fma) and two run-time
+# switches (loop form, sky mode).  The corner {serial, recursive, sky=current} is the reference's
+# serial program and is pinned byte for byte above.  The tests below walk from that corner to
+# {CUDA, iterative, sky=primary} one switch at a time, each step against reference-run output:
+#   1. loop form        recursive -> iterative with IDENTICAL random numbers: same P3 bytes;
+#   2. policy           serial -> CUDA (sky still from the current ray) against the images the
+#                       reference's own serial tracer printed (tests/golden/ref_serial_*.npz),
+#                       gated with SURVEY.md A.5's ppm_diff noise floors;
+#   3. sky mode         current -> primary: the blue channel of the sky blend is 1.0 for every
+#                       direction (camera.h:123: (1-a)*1 + a*1), so the FINAL oracle -- the exact
+#                       code path the GPU is judged by -- must still match the reference images
+#                       in blue within the floor, while red/green get whiter (SURVEY §0 finding 2);
+#                       plus known answers for the sky term and a mirror scene that separates the
+#                       two sky modes exactly.
+# What stays "parity unpinned": cuRAND's bit stream and nvcc's contraction choices (no CUDA
+# toolchain here) -- they change the noise, not these statistics.
+# ---------------------------------------------------------------------------------------
+from tests.oracle_lib import ITERATIVE, RECURSIVE, SKY_CURRENT, SKY_PRIMARY, diff_stats, p3_levels, to_levels  # noqa: E402
+
+
+def _ref_images(golden_dir):
+    meta = json.load(open(os.path.join(golden_dir, "ref_serial_320x192_100spp_50b.json")))
+    imgs = np.load(os.path.join(golden_dir, "ref_serial_320x192_100spp_50b.npz"))
+    return meta, imgs
+
+
+def test_reference_image_fixtures_are_what_the_reference_prints(golden_dir):
+    """The fixture images are outputs of the reference's serial tracer (make_golden.py); when the
+    binary built from the reference's sources is here, one of them is regenerated and compared."""
+    meta, imgs = _ref_images(golden_dir)
+    assert sorted(meta["scenes"]) == ["1", "2", "3"] and imgs["s1"].shape == (192, 320, 3)
+    # SURVEY.md A.5 measured the same floors with the reference's ppm_diff (1.408 / 2.490)
+    assert abs(meta["scenes"]["3"]["floor_mean"] - 1.408) < 0.05 and abs(meta["scenes"]["1"]["floor_mean"] - 2.490) < 0.08
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_serial_driver")
+    if not os.path.exists(drv):
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    out = subprocess.run([drv, "2", "320", "192", "100", "50"], capture_output=True, check=True).stdout
+    assert hashlib.md5(out).hexdigest() == meta["scenes"]["2"]["md5"]
+    assert np.array_equal(p3_levels(out), imgs["s2"])
+
+
+def test_loop_form_is_neutral_with_identical_random_numbers(oracle):
+    """camera.h:84-127 (iterative: running attenuation, then * sky) against the recursion of the
+    serial program (src/InOneWeekend/camera.h:137-156), SAME policy, SAME rand() stream: the draws
+    happen in the same order, only the association of the colour product differs (rounding far
+    below a level).  Pins the loop structure of the CUDA form -- depth limit, absorb -> black,
+    order of scatter and attenuation -- against the byte-exact corner."""
+    for cfg in [(3, 160, 96, 10, 50), (1, 120, 72, 4, 25), (2, 80, 48, 8, 50), (3, 64, 36, 6, 2), (2, 40, 24, 9, 1)]:
+        rec, st_r = oracle.render_serial(*cfg)
+        it, st_i = oracle.render_serial(*cfg, loop_form=ITERATIVE)
+        a, b = p3_levels(rec), p3_levels(it)
+        assert st_r == st_i, cfg                                   # same rays, same hit_world calls
+        assert np.abs(a.astype(int) - b.astype(int)).max() <= 1 and (a != b).mean() < 1e-3, cfg
+
+
+@pytest.mark.parametrize("scene_id", [1, 2, 3])
+def test_cuda_policy_with_current_ray_sky_matches_reference_images(oracle, native, golden_dir, scene_id):
+    """CUDA policy (per-pixel XORWOW, (0,1] draws, explicit fma, powf-Schlick, x,y,z cube points),
+    iterative loop, fp64, with the sky switched to the CURRENT ray == the reference serial
+    tracer's image up to Monte-Carlo noise: SURVEY.md §8c gates (1.25 x / 1.5 x the noise floor
+    between two independent renders, per-channel bias <= 0.3 level).  A wrong fuzz factor,
+    Schlick term, refraction index choice or absorb rule moves the bias by levels.
+    Measured: mean 2.46 / 1.26 / 1.41 (floors 2.47 / 1.25 / 1.40), |bias| <= 0.034."""
+    from tests.conftest import compact
+    meta, imgs = _ref_images(golden_dir)
+    m = meta["scenes"][str(scene_id)]
+    ref = imgs["s%d" % scene_id]
+    img, _ = oracle.render(64, compact(oracle.build_scene(scene_id, 64)), native.camera(64, 320, 192, 100, 50), 1227, sky_mode=SKY_CURRENT)
+    d = diff_stats(to_levels(img), ref)
+    assert d["mean"] <= 1.25 * m["floor_mean"], d
+    assert d["p99"] <= 1.5 * m["floor_p99"], d
+    assert max(abs(b) for b in d["bias"]) <= 0.3, d
+
+
+def test_cuda_policy_fp32_with_current_ray_sky_vs_reference_images(oracle, native, golden_dir):
+    """Same for the fp32 policy (GlobalFloat).  fp32 differs from the fp64 reference image by a
+    real effect of the reference's own float arithmetic: hit points on the radius-1000 ground
+    sphere carry ~6e-5 of rounding, so some scattered rays re-hit it beyond tmin = 0.001 (shadow
+    acne: 2.42 instead of 2.24 hit_world calls per ray on scene 3), which darkens the GROUND
+    rows by ~0.45 level and leaves sky rows alone.  Gate: floor gates as above, bias within 0.5
+    level and negative on the ground only."""
+    from tests.conftest import compact
+    meta, imgs = _ref_images(golden_dir)
+    m, ref = meta["scenes"]["3"], imgs["s3"]
+    img, st = oracle.render(32, compact(oracle.build_scene(3, 32)), native.camera(32, 320, 192, 100, 50), 1227, sky_mode=SKY_CURRENT)
+    lv = to_levels(img)
+    d = diff_stats(lv, ref)
+    assert d["mean"] <= 1.25 * m["floor_mean"] and d["p99"] <= 1.5 * m["floor_p99"], d
+    assert max(abs(b) for b in d["bias"]) <= 0.5, d
+    sky_rows = diff_stats(lv[:40], ref[:40])
+    assert max(abs(b) for b in sky_rows["bias"]) <= 0.15, sky_rows
+    assert 2.3 < st[1] / st[0] < 2.55
+
+
+@pytest.mark.parametrize("scene_id", [1, 2, 3])
+def test_final_cuda_oracle_matches_reference_images_in_the_sky_invariant_channel(oracle, native, golden_dir, scene_id):
+    """The oracle exactly as the GPU tests use it (primary-ray sky, camera.h:121) against the
+    reference-run images.  The blue weight of the sky blend is (1-a)*1.0 + a*1.0 = 1 for every
+    direction, so the blue channel does not depend on WHICH ray feeds the sky term: it must match
+    the reference image within the noise floor.  Red and green must be brighter (the primary ray
+    of a ground pixel looks down: whiter sky), by the amounts SURVEY §0 finding 2 describes
+    (measured +17.6 / +9.6 levels on scene 3, +13.6 / +7.3 on scene 1)."""
+    from tests.conftest import compact
+    meta, imgs = _ref_images(golden_dir)
+    m = meta["scenes"][str(scene_id)]
+    ref = imgs["s%d" % scene_id]
+    img, _, seg = oracle.render(64, compact(oracle.build_scene(scene_id, 64)), native.camera(64, 320, 192, 100, 50), 1227, segments=True)
+    lv = to_levels(img)
+    blue = diff_stats(lv[..., 2], ref[..., 2])
+    assert blue["mean"] <= 1.25 * m["floor_mean_blue"] and blue["p99"] <= 1.5 * m["floor_p99_blue"], blue
+    d = diff_stats(lv, ref)
+    assert abs(d["bias"][2]) <= 0.3, d
+    assert 5.0 < d["bias"][1] < d["bias"][0] < 25.0, d           # whiter: red gains most (sky red weight 1 - a/2)
+    # pixels whose 100 samples all missed (one hit_world call each) are the same in both modes:
+    # the primary ray IS the ray that missed
+    pure = seg == 100
+    assert pure.sum() > 2000
+    top = diff_stats(lv[pure], ref[pure])
+    assert max(abs(b) for b in top["bias"]) <= 0.3 and top["mean"] <= 0.6, top
+
+
+def test_policies_agree_when_only_the_policy_differs(oracle, native):
+    """Serial policy vs CUDA policy with the SAME loop form and the SAME (primary-ray) sky at
+    converged sample counts: block means agree to ~1 level (independent noise only)."""
+    from tests.conftest import compact
+    W, H, S, B = 48, 28, 1500, 50
+    ser = p3_levels(oracle.render_serial(3, W, H, S, B, loop_form=ITERATIVE, sky_mode=SKY_PRIMARY)[0]).astype(np.float64)
+    img, _ = oracle.render(64, compact(oracle.build_scene(3, 64)), native.camera(64, W, H, S, B), 1227)
+    cud = to_levels(img).astype(np.float64)
+    assert np.abs(ser - cud).mean() < 0.8
+    blocks = (ser - cud).reshape(4, H // 4, 4, W // 4, 3).mean(axis=(1, 3))
+    assert np.abs(blocks).max() < 1.0, blocks
+    assert np.abs((ser - cud).mean(axis=(0, 1))).max() < 0.25
+
+
+def test_sky_term_known_answers(oracle):
+    """camera.h:121-123: a = 0.5*(unit(dir).y + 1); colour = (1-a)*(1,1,1) + a*(0.5,0.7,1.0),
+    for un-normalised directions, in every policy."""
+    rng = np.random.default_rng(5)
+    dirs = [[0, 1, 0], [0, -1, 0], [1, 0, 0], [0, 0, -3], [3, 4, 0], [-13, -2, -3]] + list(rng.normal(size=(40, 3)) * rng.uniform(0.1, 50, (40, 1)))
+    for policy, tol in ((0, 1e-15), (64, 1e-15), (32, 3e-7)):
+        for d in dirs:
+            d = np.asarray(d, np.float64)
+            a = 0.5 * (d[1] / np.linalg.norm(d) + 1.0)
+            want = (1.0 - a) * np.ones(3) + a * np.array([0.5, 0.7, 1.0])
+            got = oracle.sky(policy, d)
+            assert np.allclose(got, want, rtol=0, atol=tol), (policy, d, got, want)
+            assert abs(got[2] - 1.0) <= tol                        # blue weight is 1 for every direction
+    assert np.array_equal(oracle.sky(0, [0, 1, 0]), [0.5, 0.7, 1.0]) and np.array_equal(oracle.sky(32, [0, -2, 0]), [1, 1, 1])
+
+
+def probe_scene(prec, kind):
+    """Two hand-made scenes for the sky-mode known answers: 'empty' = one tiny far-away sphere that
+    no ray meets (the C-ABI wants a non-empty table); 'mirror' = the same plus a perfect mirror
+    (metal, albedo 1, fuzz 0) of radius 6 at the look-at point, which covers the whole 20-degree
+    view from (13,2,3) (angular radius 26 degrees against 18 for the frame's corner)."""
+    dt = np.float32 if prec == 32 else np.float64
+    cr = [[2000.0, 3000.0, 500.0, 0.01]]
+    af = [[0.5, 0.5, 0.5, 0.0]]
+    ty = [0]
+    if kind == "mirror":
+        cr.append([0.0, 0.0, 0.0, 6.0]); af.append([1.0, 1.0, 1.0, 0.0]); ty.append(1)
+    n = len(ty)
+    return {"center_radius": np.array(cr, dt), "albedo_fuzz": np.array(af, dt), "refraction_index": np.zeros(n, dt),
+            "type": np.array(ty, np.int32), "valid": np.ones(n, np.int32)}
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+def test_sky_comes_from_the_primary_ray_mirror_known_answer(oracle, native, prec):
+    """camera.h:121 shades a miss with the PRIMARY ray r, not the ray that missed.  Known answer:
+    in front of a perfect mirror every path is hit -> reflect -> miss, attenuation exactly 1, so
+    with 1 sample per pixel the CUDA program's image of the mirror is BIT-IDENTICAL to the image
+    of the empty scene (same jitter and lens draws come first), while the serial program's rule
+    (sky from the current = reflected ray) gives a different picture.  Also checks the empty
+    image against the analytic gradient of the pixel-centre directions."""
+    W, H = 64, 40
+    cam = native.camera(prec, W, H, 1, 10)
+    empty, st_e = oracle.render(prec, probe_scene(prec, "empty"), cam, 1227)
+    mirror, st_m = oracle.render(prec, probe_scene(prec, "mirror"), cam, 1227)
+    assert st_e[1] == W * H and st_m[1] == 2 * W * H               # miss | hit + miss, for every pixel
+    assert np.array_equal(empty.view(np.uint8), mirror.view(np.uint8))
+    cur, _ = oracle.render(prec, probe_scene(prec, "mirror"), cam, 1227, sky_mode=SKY_CURRENT)
+    assert np.abs(cur.astype(np.float64) - mirror).mean() > 0.02    # the reflected rays see another part of the sky
+    # analytic: pixel^2 = sky(unit(pixel centre - camera centre)) up to jitter (half a pixel) and lens (radius 0.052)
+    p00, du, dv, c = (np.array(list(x), np.float64) for x in (cam.pixel00_loc, cam.pixel_delta_u, cam.pixel_delta_v, cam.center))
+    jj, ii = np.mgrid[0:H, 0:W]
+    d = p00 + ii[..., None] * du + jj[..., None] * dv - c
+    a = 0.5 * (d[..., 1] / np.linalg.norm(d, axis=-1) + 1.0)
+    want = (1.0 - a)[..., None] * np.ones(3) + a[..., None] * np.array([0.5, 0.7, 1.0])
+    # |d sky / d uy| <= 0.25 per unit of uy; a pixel is |dv|/10 of uy, the lens 0.052/10
+    slack = 0.25 * (np.linalg.norm(dv) + np.linalg.norm(du) + 0.06) / 10.0
+    assert np.abs(empty.astype(np.float64) ** 2 - want).max() <= slack
