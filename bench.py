@@ -18,7 +18,17 @@ Prints ONE JSON line on rank 0.  Extra objects:
                 figures for the whole step (all launches) are under "step".
   cpu_baseline  the reference's serial tracer (oracle/_ref, built from the reference's own
                 sources) or, if absent, the oracle's serial port, timed on this host (1 thread)
-                on a bounded sample of the same workload
+                on a bounded sample of the same workload; "config1" inside it is BASELINE.json
+                configs[0] in full (serial CPU, scene 1, 320x192, 10 spp, 25 bounces)
+  scaling       what bounds strong scaling of this path: a pixel's samples are ONE
+                sequential RNG chain, so no rank finishes before prepass + its longest chain x
+                the latency of a lone ray's trip: "floor_ms" (measured here: the longest chain is
+                counted on the device, the trip latency is timed on a 1-pixel frame); per-rank
+                kernel_ms and gather_ms (events around the collective) when the run is distributed
+
+Launched by torch.distributed.run (RANK/WORLD_SIZE in the environment) the run is distributed
+even at WORLD_SIZE=1: process group "nccl" (= RCCL), the strip gather, the all_reduce of the
+timings and the barriers all execute, so the N>1 code path can be exercised on a one-GPU box.
 """
 import argparse
 import json
@@ -95,14 +105,50 @@ def cpu_baseline(args):
     return dict({"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": sample + "; oracle serial port", "seconds": dt}, **host_cpu())
 
 
+def cpu_baseline_config1():
+    """BASELINE.json configs[0] in full: the reference's serial tracer, scene 1, 320x192, 10 spp,
+    depth 25, one thread ("C1 in full")."""
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_serial_driver")
+    cfg = (1, 320, 192, 10, 25)
+    rays = cfg[1] * cfg[2] * cfg[3]
+    what = "BASELINE.json configs[0]: serial CPU, scene 1, 320x192, 10 spp, depth 25, full frame"
+    if os.path.exists(drv):
+        t0 = time.perf_counter()
+        r = subprocess.run([drv] + [str(x) for x in cfg], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        dt = time.perf_counter() - t0
+        if r.returncode == 0 and r.stdout.startswith(b"P3"):
+            return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference", "sample": what, "seconds": dt}
+    from tests.oracle_lib import Oracle
+    t0 = time.perf_counter()
+    Oracle().render_serial(*cfg)
+    dt = time.perf_counter() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": what + "; oracle serial port", "seconds": dt}
+
+
 def pmc_traffic(args):
-    """HBM bytes per render launch from a committed rocprofv3 --pmc pass (profiles/), or None."""
+    """HBM bytes of the main render launch from the committed rocprofv3 --pmc passes (profiles/traffic.json):
+    (total with the gfx950 x2 FETCH correction, fetch bytes raw, write bytes), or (None, None, None)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
-        return None
+        return None, None, None
     key = "s%d_%dx%d_%dspp_%db_f%d" % (args.scene_id, args.width, args.height, args.samples, args.bounces, args.precision)
     e = json.load(open(path)).get(key, {})
-    return e.get("hbm_bytes_main_launch", e.get("hbm_bytes_per_launch"))
+    f, w = e.get("main_launch_FETCH_SIZE_KB"), e.get("main_launch_WRITE_SIZE_KB")
+    return (e.get("hbm_bytes_main_launch", e.get("hbm_bytes_per_launch")), f * 1024.0 if f is not None else None, w * 1024.0 if w is not None else None)
+
+
+def lone_ray_trip_us(rt, device_index, prec, scene, args):
+    """Latency of one path segment of a ray that has a wave to itself (what bounds the end of every
+    shard): a 1-pixel frame of this scene, a few hundred samples, HIP-event time /
+    segments.  The pixel is the frame's centre pixel region seen through the same camera maths."""
+    S = 400
+    with rt.Renderer(device_index, prec) as r:
+        r.set_camera(rt.camera(prec, 1, 1, S, args.bounces))
+        r.set_scene(scene)
+        r.init_rng(1227)
+        segs = r.count_segments(0)
+        best = min(r.render(0) for _ in range(5))
+    return (best * 1e3 / segs if segs else None), segs
 
 
 def main():
@@ -110,6 +156,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # under torch.distributed.run the job is distributed whatever its size (see the docstring)
+    distributed = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ)
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
@@ -121,7 +169,7 @@ def main():
     backend = os.environ.get("RTIOW_BENCH_BACKEND", "nccl")
     device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
-    if world > 1:
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
@@ -147,44 +195,66 @@ def main():
     r.set_scene_source(rt.SCENE_LDS if args.scene_source == "lds" else rt.SCENE_SCALAR)
     r.set_schedule({"sorted": rt.SCHED_SORTED, "persistent": rt.SCHED_PERSISTENT, "static": rt.SCHED_STATIC}[args.schedule])
     r.set_shard(rank, world, args.strip_rows)
-    gather = StripGather(W, H, rank, world, args.strip_rows, tdtype, "cuda:%d" % device_index, stage_via_cpu=(backend != "nccl"))
+    gather = StripGather(W, H, rank, world, args.strip_rows, tdtype, "cuda:%d" % device_index, stage_via_cpu=(backend != "nccl"),
+                         always_collective=distributed)
     view = gather.local_view()
     r.bind_framebuffer(view.data_ptr(), view.numel() * view.element_size())
     r.init_rng(1227)                                   # untimed, like main.cu:326-330
     segments = r.count_segments(args.threads)          # untimed; also a first warm launch
     nspheres = r.stats()["num_spheres"]
 
+    chain_main = int(r.stats()["max_chain_main"])      # this rank's longest per-pixel chain in the main launch
+    trip_us, trip_segments = lone_ray_trip_us(rt, device_index, prec, scene, args)
+
     main_ms = []
+    gather_events = []
 
     def step(timed):
         ms = r.render(args.threads, sync=timed)        # HIP events on the launch stream
         if timed:
             main_ms.append(r.stats()["main_ms"])        # the main launch alone (events around it)
-        if world > 1:
-            gather.gather()
+        if distributed:
+            if timed:                                   # events around the collective, on the stream it is enqueued on
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                gather.gather()
+                e1.record(stream)
+                gather_events.append((e0, e1))
+            else:
+                gather.gather()
         return ms
 
     for _ in range(args.warmup):
         step(False)
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         kernel_ms.append(step(True))
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_events])) if gather_events else None
 
-    if world > 1:
-        t = torch.tensor([elapsed, float(np.mean(kernel_ms)), float(segments)], dtype=torch.float64, device="cuda")
+    st_local = r.stats()
+    floor_local = float(st_local["prepass_ms"]) + chain_main * (trip_us or 0.0) * 1e-3
+    if distributed:
+        t = torch.tensor([elapsed, float(np.mean(kernel_ms)), float(segments), gather_ms or 0.0, floor_local, float(chain_main)], dtype=torch.float64, device="cuda")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        per_rank = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(per_rank, t)
         elapsed, kernel_mean_max, segments_total = float(tmax[0]), float(tmax[1]), float(tsum[2])
+        gather_ms_max, floor_ms, chain_max = float(tmax[3]), float(tmax[4]), int(tmax[5])
+        kernel_ms_per_rank = [round(float(x[1]), 4) for x in per_rank]
+        gather_ms_per_rank = [round(float(x[3]), 4) for x in per_rank]
     else:
         kernel_mean_max, segments_total = float(np.mean(kernel_ms)), float(segments)
+        gather_ms_max, floor_ms, chain_max = None, floor_local, chain_main
+        kernel_ms_per_rank, gather_ms_per_rank = [round(float(np.mean(kernel_ms)), 4)], None
 
     if rank == 0:
         rays = float(W) * H * S
@@ -207,6 +277,7 @@ def main():
         my_pixels = my_rays / S
         state_bytes = ((48 if prec == 32 else 64) + 4) if st["phases"] == 2 else 24
         fb_bytes = my_pixels * (3 * (4 if prec == 32 else 8) + state_bytes)
+        traffic, fetch_b, write_b = pmc_traffic(args) if world == 1 and args.schedule == "sorted" else (None, None, None)
         line = {
             "metric": "Mrays/s (= W x H x samples / render time)",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -215,13 +286,14 @@ def main():
             "config": {"workload": "scene %d (%d spheres), %dx%d, %d spp, %d bounces, XORWOW seed 1227" % (args.scene_id, nspheres, W, H, S, B),
                        "scene_id": args.scene_id, "spheres": nspheres, "width": W, "height": H, "samples": S, "bounces": B,
                        "threads": args.threads, "scene_source": args.scene_source, "schedule": args.schedule,
-                       "sharding": "interleaved %d-row strips, gather to rank 0 inside the step" % args.strip_rows if world > 1 else "none",
-                       "backend": backend if world > 1 else None},
+                       "sharding": "interleaved %d-row strips, gather to rank 0 inside the step" % args.strip_rows if distributed else "none",
+                       "backend": backend if distributed else None},
             "kernel_ms_mean": round(kms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
             "kernel_ms_mean_max_over_ranks": round(kernel_mean_max, 4),
             "segments_per_ray": round(segments_total / rays, 4),
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args) if world == 1 and args.schedule == "sorted" else None,   # the PMC passes: one GPU, full frame, default schedule
+                         "frac": round(achieved / peak, 4), "traffic": traffic,   # the PMC passes: one GPU, full frame, default schedule
+                         "fetch_bytes": fetch_b, "write_bytes": write_b,   # the same passes, raw FETCH_SIZE / WRITE_SIZE of the main launch (the sorted schedule stores pixels in cost order: writes exceed the 12 B/pixel framebuffer)
                          "kernel": "%s<%s>" % ("render_kernel" if args.schedule == "static" else "render_persistent_kernel", "float" if prec == 32 else "double"),
                          "launch_ms_mean": round(mms, 4), "launch_ms_min": round(float(np.min(main_ms)), 4),
                          "algorithmic_flops_per_launch": flops, "segments_in_launch": int(st["segments_main"]),
@@ -233,11 +305,19 @@ def main():
                      "algorithmic_flops": flops_step, "achieved_TFLOPs": round(flops_step / (kms * 1e-3) / 1e12, 3),
                      "frac_of_peak": round(flops_step / (kms * 1e-3) / 1e12 / peak, 4)},
         }
+        line["scaling_detail"] = {
+            "floor_ms": round(floor_ms, 4), "floor_is": "prepass_ms + longest per-pixel chain of the main launch x lone-ray trip latency, max over ranks",
+            "longest_chain_segments": chain_max, "lone_ray_trip_us": round(trip_us, 4) if trip_us else None,
+            "lone_ray_probe": "1x1 frame, 400 spp, %d segments" % trip_segments,
+            "kernel_ms_per_rank": kernel_ms_per_rank, "gather_ms_per_rank": gather_ms_per_rank,
+            "gather_ms": round(gather_ms_max, 4) if gather_ms_max is not None else None,
+            "gather_bytes_total": int(W) * H * 3 * (4 if prec == 32 else 8) if distributed else 0}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
+            line["cpu_baseline"]["config1"] = cpu_baseline_config1()
         print(json.dumps(line), flush=True)
     r.close()
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

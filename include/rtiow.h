@@ -13,7 +13,9 @@
  * RTIOW_E_* code for argument errors); rtiow_last_error_string() gives the text that the
  * reference's CUDA_SAFE_CALL (main.cu:14-21) would have printed.  The caller owns host
  * memory; the library owns device memory behind the opaque handle.  A handle is not
- * thread-safe.  One handle == one GPU; multi-GPU jobs use one handle per rank (process).
+ * thread-safe.  One handle == one GPU; multi-GPU jobs use either one handle per rank (process;
+ * raytracingincuda_amd/distributed.py gathers with torch.distributed) or one rtiow_group (below)
+ * in a single process.
  */
 #ifndef RTIOW_H
 #define RTIOW_H
@@ -25,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RTIOW_ABI_VERSION 1
+#define RTIOW_ABI_VERSION 2
 
 #define RTIOW_E_BADARG   (-1)
 #define RTIOW_E_STATE    (-2)   /* call order violated (e.g. render before set_scene) */
@@ -99,6 +101,9 @@ typedef struct {
                                   * render_kernel): the dominant kernel of the roofline      */
     uint64_t segments_prepass;   /* last rtiow_count_segments: hit_world calls per launch   */
     uint64_t segments_main;
+    uint64_t max_chain_prepass;  /* last rtiow_count_segments: the longest per-pixel chain of      */
+    uint64_t max_chain_main;     /* segments in each launch (a pixel's samples are sequential: one
+                                  * RNG stream, so no schedule finishes before its longest chain)  */
 } rtiow_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------
@@ -144,6 +149,13 @@ int rtiow_init_rng(rtiow_handle h, uint64_t seed);
  * makes the call asynchronous on the handle's stream. */
 int rtiow_render(rtiow_handle h, int threads_per_block_row, float* kernel_ms);
 
+/* The two halves of a timed rtiow_render, for callers that drive several GPUs from one thread
+ * (rtiow_group_*, below): rtiow_render_async enqueues start event, launches and stop event on the
+ * handle's stream and returns; rtiow_render_wait blocks on the stop event and returns the
+ * HIP-event time of the kernels alone (the same figure rtiow_render reports). */
+int rtiow_render_async(rtiow_handle h, int threads_per_block_row);
+int rtiow_render_wait(rtiow_handle h, float* kernel_ms);
+
 /* Same render with a path-segment counter (hit_world calls, hittable.h:80) added: untimed,
  * used by bench.py for the algorithmic-flop figure and by tests against the oracle's count.
  * The image it leaves in the framebuffer is identical to rtiow_render's. */
@@ -163,6 +175,8 @@ int rtiow_set_scene_source(rtiow_handle h, int scene_source /* RTIOW_SCENE_* */)
 int rtiow_set_schedule(rtiow_handle h, int schedule /* RTIOW_SCHED_* */, int waves_per_simd);
 int rtiow_get_stats(rtiow_handle h, rtiow_stats* out);
 int rtiow_synchronize(rtiow_handle h);
+int rtiow_stream(rtiow_handle h, void** hip_stream);   /* the hipStream_t the handle launches on */
+int rtiow_device(rtiow_handle h, int* device);
 
 /* ---- test hooks (used by tests/ only): device RNG states after rtiow_init_rng, as
  * local_pixels x 6 uint32 {v0..v4,d}; and elementwise device arithmetic probes that the
@@ -178,6 +192,64 @@ int rtiow_debug_ops(rtiow_handle h, int op, size_t n, const void* a, const void*
  * them: from its committed constant A^(2^67), or from_scratch != 0 from the one-step matrix A.
  * Host arithmetic only (no GPU needed).  Returns the number of matrices. */
 int rtiow_debug_jump_matrices(uint32_t* out_words, size_t cap_words, int from_scratch);
+
+/* ======================================================================================
+ * Multi-GPU inside one process (new work: the reference is single-GPU, main.cu:81).
+ *
+ * A group is ngpus handles -- one per device, each with its own stream -- that render the
+ * interleaved row strips of ONE image (rtiow_set_shard(rank, ngpus, strip_rows)) and exchange
+ * them exactly once, after the render: every device sends its strips to device 0 over RCCL
+ * (ncclCommInitAll + one ncclGroupStart/End of ncclSend/ncclRecv pairs over xGMI; librccl.so is
+ * dlopen'ed on first use) or, when RCCL is unavailable, with hipMemcpyPeerAsync; device 0
+ * de-interleaves the strips into the full image.  The assembled image equals the single-GPU
+ * image bit for bit (RNG streams are keyed by the global pixel index).
+ *
+ * The calls mirror the single-handle ones phase by phase, so a host main() keeps the reference's
+ * ordering (main.cu:81-400): create, set_camera, set_scene, init_rng, render, read_framebuffer.
+ * rtiow_group_render's kernel_ms is the reference's render_only figure for the slowest device;
+ * the exchange is NOT inside it (it belongs to the read-back, like the managed-memory read at
+ * main.cu:373) and is reported separately in rtiow_group_stats.
+ * ====================================================================================== */
+#define RTIOW_GATHER_AUTO 0   /* RCCL if it loads and initialises, else peer copies */
+#define RTIOW_GATHER_RCCL 1   /* RCCL or fail                                        */
+#define RTIOW_GATHER_PEER 2   /* hipMemcpyPeerAsync per device                       */
+#define RTIOW_GROUP_MAX_STATS 16
+
+typedef struct rtiow_group_s* rtiow_group;
+
+typedef struct {
+    int32_t  ngpus, strip_rows;
+    int32_t  gather_mode;                       /* transport of the last gather: RTIOW_GATHER_RCCL | _PEER (0: none yet) */
+    int32_t  rccl_version;                      /* ncclGetVersion() when RCCL is in use, else 0 */
+    double   kernel_ms[RTIOW_GROUP_MAX_STATS];  /* per device: HIP-event time of its own kernels, last render */
+    double   kernel_ms_max;                     /* = what rtiow_group_render returned */
+    double   gather_ms;                         /* HIP events on device 0 around exchange + de-interleave, opened when the last render finished */
+    uint64_t gather_bytes;                      /* bytes that arrived on device 0 */
+} rtiow_group_stats;
+
+/* devices == NULL: devices 0..ngpus-1.  A device may be listed more than once (ranks then share
+ * it and the exchange uses copies: RCCL needs distinct devices) -- used to test the N-rank logic
+ * on a one-GPU box. */
+int rtiow_group_create(int ngpus, const int* devices, int precision, int strip_rows, int gather, rtiow_group* out);
+int rtiow_group_destroy(rtiow_group g);
+const char* rtiow_group_last_error_string(rtiow_group g);
+int rtiow_group_size(rtiow_group g);
+int rtiow_group_member(rtiow_group g, int rank, rtiow_handle* out);   /* borrowed: knobs, per-device stats */
+int rtiow_group_set_scene(rtiow_group g, int n, const void* center_radius, const void* albedo_fuzz,
+                          const void* refraction_index, const int32_t* type, const int32_t* valid);
+int rtiow_group_set_camera(rtiow_group g, const void* camera);
+int rtiow_group_set_scene_source(rtiow_group g, int scene_source);
+int rtiow_group_set_schedule(rtiow_group g, int schedule, int waves_per_simd);
+int rtiow_group_init_rng(rtiow_group g, uint64_t seed);
+int rtiow_group_render(rtiow_group g, int threads_per_block_row, float* kernel_ms);
+/* The exchange alone (device 0 then holds the full image, rtiow_group_framebuffer_device_ptr). */
+int rtiow_group_gather(rtiow_group g);
+int rtiow_group_framebuffer_device_ptr(rtiow_group g, void** device_ptr, size_t* bytes);
+/* gather + D2H of the full width*height*3 T image. */
+int rtiow_group_read_framebuffer(rtiow_group g, void* host_rgb, size_t bytes);
+int rtiow_group_get_stats(rtiow_group g, rtiow_group_stats* out);
+/* Why RTIOW_GATHER_AUTO fell back to peer copies ("" if it did not). */
+const char* rtiow_group_transport_note(rtiow_group g);
 
 #ifdef __cplusplus
 }

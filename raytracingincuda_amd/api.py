@@ -23,6 +23,8 @@ import numpy as np
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 SCENE_LDS, SCENE_SCALAR, SCENE_LDS_EXACT = 0, 1, 2
 SCHED_STATIC, SCHED_PERSISTENT, SCHED_SORTED = 0, 1, 2
+GATHER_AUTO, GATHER_RCCL, GATHER_PEER = 0, 1, 2
+GROUP_MAX_STATS = 16
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIBDIR = os.path.join(_PKG, "lib")
@@ -62,7 +64,14 @@ class Stats(ctypes.Structure):
                 ("scene_source", ctypes.c_int32),
                 ("schedule", ctypes.c_int32), ("grid_blocks", ctypes.c_int32), ("phases", ctypes.c_int32),
                 ("prepass_samples", ctypes.c_int32), ("prepass_ms", ctypes.c_double), ("main_ms", ctypes.c_double),
-                ("segments_prepass", ctypes.c_uint64), ("segments_main", ctypes.c_uint64)]
+                ("segments_prepass", ctypes.c_uint64), ("segments_main", ctypes.c_uint64),
+                ("max_chain_prepass", ctypes.c_uint64), ("max_chain_main", ctypes.c_uint64)]
+
+
+class GroupStats(ctypes.Structure):
+    _fields_ = [("ngpus", ctypes.c_int32), ("strip_rows", ctypes.c_int32), ("gather_mode", ctypes.c_int32),
+                ("rccl_version", ctypes.c_int32), ("kernel_ms", ctypes.c_double * GROUP_MAX_STATS),
+                ("kernel_ms_max", ctypes.c_double), ("gather_ms", ctypes.c_double), ("gather_bytes", ctypes.c_uint64)]
 
 
 # Every symbol include/rtiow.h declares (tests check that the built library exports them all).
@@ -72,6 +81,11 @@ HIP_SYMBOLS = [
     "rtiow_init_rng", "rtiow_render", "rtiow_count_segments", "rtiow_bind_framebuffer", "rtiow_framebuffer_device_ptr",
     "rtiow_read_framebuffer", "rtiow_set_scene_source", "rtiow_set_schedule", "rtiow_get_stats", "rtiow_synchronize",
     "rtiow_debug_read_rng", "rtiow_debug_timeline", "rtiow_debug_ops", "rtiow_debug_jump_matrices",
+    "rtiow_render_async", "rtiow_render_wait", "rtiow_stream", "rtiow_device",
+    "rtiow_group_create", "rtiow_group_destroy", "rtiow_group_last_error_string", "rtiow_group_size", "rtiow_group_member",
+    "rtiow_group_set_scene", "rtiow_group_set_camera", "rtiow_group_set_scene_source", "rtiow_group_set_schedule",
+    "rtiow_group_init_rng", "rtiow_group_render", "rtiow_group_gather", "rtiow_group_framebuffer_device_ptr",
+    "rtiow_group_read_framebuffer", "rtiow_group_get_stats", "rtiow_group_transport_note",
 ]
 HOST_SYMBOLS = [
     "rtiow_host_scene_slots", "rtiow_host_build_scene", "rtiow_host_camera", "rtiow_host_ppm_filename",
@@ -144,6 +158,29 @@ def load_hip_library():
         lib.rtiow_debug_read_rng.argtypes = [H, ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t]
         lib.rtiow_debug_timeline.argtypes = [H, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
         lib.rtiow_debug_ops.argtypes = [H, ctypes.c_int, ctypes.c_size_t, vp, vp, vp, vp]
+        lib.rtiow_render_async.argtypes = [H, ctypes.c_int]
+        lib.rtiow_render_wait.argtypes = [H, ctypes.POINTER(ctypes.c_float)]
+        lib.rtiow_stream.argtypes = [H, ctypes.POINTER(vp)]
+        lib.rtiow_device.argtypes = [H, ctypes.POINTER(ctypes.c_int)]
+        G = ctypes.c_void_p
+        lib.rtiow_group_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(G)]
+        lib.rtiow_group_destroy.argtypes = [G]
+        lib.rtiow_group_last_error_string.argtypes = [G]
+        lib.rtiow_group_last_error_string.restype = ctypes.c_char_p
+        lib.rtiow_group_transport_note.argtypes = [G]
+        lib.rtiow_group_transport_note.restype = ctypes.c_char_p
+        lib.rtiow_group_size.argtypes = [G]
+        lib.rtiow_group_member.argtypes = [G, ctypes.c_int, ctypes.POINTER(H)]
+        lib.rtiow_group_set_scene.argtypes = [G, ctypes.c_int, vp, vp, vp, i32p, i32p]
+        lib.rtiow_group_set_camera.argtypes = [G, vp]
+        lib.rtiow_group_set_scene_source.argtypes = [G, ctypes.c_int]
+        lib.rtiow_group_set_schedule.argtypes = [G, ctypes.c_int, ctypes.c_int]
+        lib.rtiow_group_init_rng.argtypes = [G, ctypes.c_uint64]
+        lib.rtiow_group_render.argtypes = [G, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+        lib.rtiow_group_gather.argtypes = [G]
+        lib.rtiow_group_framebuffer_device_ptr.argtypes = [G, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
+        lib.rtiow_group_read_framebuffer.argtypes = [G, vp, ctypes.c_size_t]
+        lib.rtiow_group_get_stats.argtypes = [G, ctypes.POINTER(GroupStats)]
         _hip = lib
     return _hip
 
@@ -400,3 +437,93 @@ class Renderer:
         out = np.empty_like(a)
         self._check(self._lib.rtiow_debug_ops(self._h, op, a.size, a.ctypes.data, b.ctypes.data, c.ctypes.data, out.ctypes.data))
         return out
+
+
+class RendererGroup:
+    """Several GPUs of one node driven from this process (rtiow_group_*, include/rtiow.h): interleaved
+    row strips, one exchange to device 0 after the render (RCCL, or peer copies), de-interleaved there.
+    `devices` may repeat a device: the ranks then share it (how the N-rank logic is tested on one GPU)."""
+
+    def __init__(self, ngpus=1, precision=32, strip_rows=8, gather=GATHER_AUTO, devices=None):
+        self._lib = load_hip_library()
+        self.precision, self.dtype, self.ngpus = precision, _dtype(precision), int(ngpus)
+        self._g = ctypes.c_void_p()
+        devs = (ctypes.c_int * self.ngpus)(*[int(d) for d in devices]) if devices is not None else None
+        if devices is not None and len(devices) != self.ngpus:
+            raise ValueError("devices must list one device per rank")
+        rc = self._lib.rtiow_group_create(self.ngpus, devs, int(precision), int(strip_rows), int(gather), ctypes.byref(self._g))
+        if rc:
+            self._g = None
+            raise RtiowError(rc, "rtiow_group_create(%d GPUs) failed -- are that many GPUs visible?" % self.ngpus)
+        self.width = self.height = 0
+
+    def _check(self, rc):
+        if rc:
+            raise RtiowError(rc, self._lib.rtiow_group_last_error_string(self._g).decode(errors="replace"))
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._lib.rtiow_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_scene(self, scene):
+        dt = self.dtype
+        cr = np.ascontiguousarray(scene["center_radius"], dt)
+        af = np.ascontiguousarray(scene["albedo_fuzz"], dt)
+        ri = np.ascontiguousarray(scene["refraction_index"], dt)
+        ty = np.ascontiguousarray(scene["type"], np.int32)
+        va = np.ascontiguousarray(scene["valid"], np.int32) if scene.get("valid") is not None else None
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        self._check(self._lib.rtiow_group_set_scene(self._g, len(ty), cr.ctypes.data, af.ctypes.data, ri.ctypes.data,
+                                                    ty.ctypes.data_as(i32p), va.ctypes.data_as(i32p) if va is not None else None))
+
+    def set_camera(self, cam):
+        want = CameraF64 if self.precision == 64 else CameraF32
+        if not isinstance(cam, want):
+            raise TypeError("camera precision does not match the group")
+        self._check(self._lib.rtiow_group_set_camera(self._g, ctypes.addressof(cam)))
+        self.width, self.height = cam.img_width, cam.img_height
+
+    def set_scene_source(self, source):
+        self._check(self._lib.rtiow_group_set_scene_source(self._g, source))
+
+    def set_schedule(self, schedule, waves_per_simd=0):
+        self._check(self._lib.rtiow_group_set_schedule(self._g, schedule, waves_per_simd))
+
+    def init_rng(self, seed=1227):
+        self._check(self._lib.rtiow_group_init_rng(self._g, ctypes.c_uint64(seed)))
+
+    def render(self, threads=8):
+        """All devices render their strips; returns the slowest device's HIP-event kernel time (ms)."""
+        ms = ctypes.c_float(0)
+        self._check(self._lib.rtiow_group_render(self._g, int(threads), ctypes.byref(ms)))
+        return ms.value
+
+    def gather(self):
+        self._check(self._lib.rtiow_group_gather(self._g))
+
+    def read_framebuffer(self):
+        """Exchange + de-interleave on device 0, then the full [H, W, 3] image."""
+        out = np.empty((self.height, self.width, 3), self.dtype)
+        self._check(self._lib.rtiow_group_read_framebuffer(self._g, out.ctypes.data, out.nbytes))
+        return out
+
+    def stats(self):
+        st = GroupStats()
+        self._check(self._lib.rtiow_group_get_stats(self._g, ctypes.byref(st)))
+        d = {name: getattr(st, name) for name, _ in GroupStats._fields_ if name != "kernel_ms"}
+        d["kernel_ms"] = [st.kernel_ms[k] for k in range(min(st.ngpus, GROUP_MAX_STATS))]
+        d["transport_note"] = self._lib.rtiow_group_transport_note(self._g).decode(errors="replace")
+        return d

@@ -54,7 +54,7 @@ def build_stats(verbose=True):
     (lib/librtiow_hip_stats.so, -DRTIOW_PATH_STATS; used by scripts/path_stats_probe.py only)."""
     os.makedirs(LIB, exist_ok=True)
     out = os.path.join(LIB, "librtiow_hip_stats.so")
-    _run([_hipcc()] + HIP_FLAGS + ["-DRTIOW_PATH_STATS", "-o", out, os.path.join(CSRC, "rtiow_hip.hip")], verbose)
+    _run([_hipcc()] + HIP_FLAGS + ["-DRTIOW_PATH_STATS", "-o", out, os.path.join(CSRC, "rtiow_hip.hip"), os.path.join(CSRC, "rtiow_group.hip"), "-ldl"], verbose)
     return out
 
 
@@ -64,10 +64,11 @@ def build(force=False, verbose=True):
     headers = [os.path.join(INC, "rtiow.h"), os.path.join(INC, "rtiow_host.h")]
     me = os.path.abspath(__file__)
 
-    hip_src = os.path.join(CSRC, "rtiow_hip.hip")
+    hip_srcs = [os.path.join(CSRC, "rtiow_hip.hip"), os.path.join(CSRC, "rtiow_group.hip")]
     hip_so = os.path.join(LIB, "librtiow_hip.so")
-    if force or _newer(hip_so, [hip_src, me] + headers):
-        _run([_hipcc()] + HIP_FLAGS + ["-o", hip_so, hip_src], verbose)
+    if force or _newer(hip_so, hip_srcs + [me, os.path.join(CSRC, "xorwow_jump67.inc")] + headers):
+        # librccl is NOT linked: rtiow_group.hip dlopens it on first use (-ldl for old glibc)
+        _run([_hipcc()] + HIP_FLAGS + ["-o", hip_so] + hip_srcs + ["-ldl"], verbose)
 
     host_src = os.path.join(CSRC, "host", "rtiow_host.cpp")
     host_so = os.path.join(LIB, "librtiow_host.so")

@@ -30,6 +30,13 @@ struct Options {
     bool stats = false;
     bool binary_ppm = false;
     int schedule = RTIOW_SCHED_SORTED;
+    // multi-GPU (not in the reference, which is cudaSetDevice(0), main.cu:81): optional, and the
+    // default output does not change.  --gpus N renders interleaved row strips on devices 0..N-1 of
+    // this node inside this process and gathers them on device 0 (rtiow_group_*, include/rtiow.h).
+    int gpus = 0;                       // 0: flag absent -> the single-handle path
+    std::vector<int> devices;           // --devices a,b,c: explicit device per rank (a device may repeat)
+    int gather = RTIOW_GATHER_AUTO;
+    int strip_rows = 0;                 // 0: 8 rows for N <= 2, 2 rows above
 };
 
 const char* kUsage =
@@ -72,7 +79,8 @@ Options parse(int argc, char** argv) {
         if (eq != std::string::npos) { value = name.substr(eq + 1); name = name.substr(0, eq); have_value = true; }
         if (name == "stats") { o.stats = true; continue; }
         const bool known = name == "scene_id" || name == "width" || name == "height" || name == "samples" ||
-                           name == "bounces" || name == "threads" || name == "scene_source" || name == "ppm_format" || name == "schedule";
+                           name == "bounces" || name == "threads" || name == "scene_source" || name == "ppm_format" || name == "schedule" ||
+                           name == "gpus" || name == "devices" || name == "gather" || name == "strip_rows";
         if (!known) parse_abort("Option '" + name + "' does not exist");
         if (!have_value) {
             if (k + 1 >= argc) parse_abort("Option '" + name + "' is missing an argument");
@@ -91,6 +99,25 @@ Options parse(int argc, char** argv) {
             else parse_abort("Argument '" + value + "' failed to parse");
             continue;
         }
+        if (name == "gather") {
+            if (value == "auto") o.gather = RTIOW_GATHER_AUTO;
+            else if (value == "rccl") o.gather = RTIOW_GATHER_RCCL;
+            else if (value == "peer") o.gather = RTIOW_GATHER_PEER;
+            else parse_abort("Argument '" + value + "' failed to parse");
+            continue;
+        }
+        if (name == "devices") {
+            o.devices.clear();
+            size_t pos = 0;
+            while (pos <= value.size()) {
+                const size_t comma = value.find(',', pos);
+                const std::string tok = value.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+                o.devices.push_back(parse_int(name, tok));
+                if (comma == std::string::npos) break;
+                pos = comma + 1;
+            }
+            continue;
+        }
         if (name == "ppm_format") {
             if (value == "p3") o.binary_ppm = false;
             else if (value == "p6") o.binary_ppm = true;
@@ -103,6 +130,8 @@ Options parse(int argc, char** argv) {
         else if (name == "height") o.height = v;
         else if (name == "samples") o.samples = v;
         else if (name == "bounces") o.bounces = v;
+        else if (name == "gpus") o.gpus = v;
+        else if (name == "strip_rows") o.strip_rows = v;
         else o.threads = v;
     }
     return o;
@@ -115,6 +144,88 @@ void check(rtiow_handle h, int rc) {
     std::exit(rc);
 }
 
+void check_group(rtiow_group g, int rc) {
+    if (rc == 0) return;
+    std::fprintf(stderr, "%s\n", g ? rtiow_group_last_error_string(g) : "HIP_SAFE_CALL: device initialisation failed");
+    std::exit(rc);
+}
+
+// --gpus N: the same phases as main() below, each through the group twin of the call.
+int main_multi_gpu(const Options& opt) {
+    const int precision = RTIOW_PRECISION;
+    const size_t elem = precision == 64 ? 8 : 4;
+    const int n = opt.devices.empty() ? opt.gpus : (int)opt.devices.size();
+    if (n < 1 || (opt.gpus > 0 && !opt.devices.empty() && opt.gpus != n)) {
+        std::fputs("Error: --gpus must be >= 1 and match --devices.\n", stderr);
+        return 1;
+    }
+    const int strip_rows = opt.strip_rows > 0 ? opt.strip_rows : (n <= 2 ? 8 : 2);
+    rtiow_group g = nullptr;
+    int rc = rtiow_group_create(n, opt.devices.empty() ? nullptr : opt.devices.data(), precision, strip_rows, opt.gather, &g);   // main.cu:81-92, per device
+    if (rc) { std::fprintf(stderr, "HIP_SAFE_CALL: cannot open %d device(s) (error %d)\n", n, rc); return rc; }
+    const auto e2e_start = std::chrono::steady_clock::now();                 // main.cu:95
+    auto lap = [last = e2e_start]() mutable {
+        const auto now = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(now - last).count();
+        last = now;
+        return ms;
+    };
+    rtiow_camera_f32 cam32; rtiow_camera_f64 cam64;
+    void* cam = precision == 64 ? (void*)&cam64 : (void*)&cam32;
+    if (rtiow_host_camera(precision, opt.width, opt.height, opt.samples, opt.bounces, cam) != 0) {
+        std::fputs("Error: invalid image size.\n", stderr);
+        return 1;
+    }
+    check_group(g, rtiow_group_set_camera(g, cam));
+    check_group(g, rtiow_group_set_scene_source(g, opt.scene_source));
+    check_group(g, rtiow_group_set_schedule(g, opt.schedule, 0));
+    const int slots = rtiow_host_scene_slots(opt.scene_id);
+    std::vector<unsigned char> cr(elem * 4 * slots), af(elem * 4 * slots), ri(elem * slots);
+    std::vector<int32_t> type(slots), valid(slots);
+    rtiow_host_build_scene(opt.scene_id, precision, cr.data(), af.data(), ri.data(), type.data(), valid.data());
+    check_group(g, rtiow_group_set_scene(g, slots, cr.data(), af.data(), ri.data(), type.data(), valid.data()));
+    const double t_setup = lap();
+    check_group(g, rtiow_group_init_rng(g, 1227));
+    const double t_rng = lap();
+    float render_ms = 0;                                                     // max over devices of the kernel-only event time
+    check_group(g, rtiow_group_render(g, opt.threads, &render_ms));
+    std::printf("%15.8f,", (double)render_ms);
+    std::fflush(stdout);
+    const double t_render = lap();
+    char name[256];
+    rtiow_host_ppm_filename(precision, opt.scene_id, opt.width, opt.height, opt.samples, opt.bounces, opt.threads, name, sizeof name);
+    std::vector<unsigned char> rgb(elem * 3 * (size_t)opt.width * opt.height);
+    check_group(g, rtiow_group_read_framebuffer(g, rgb.data(), rgb.size()));   // the one exchange + de-interleave on device 0 + D2H
+    const double t_read = lap();
+    const int wrc = opt.binary_ppm ? rtiow_host_write_ppm_binary(name, precision, opt.width, opt.height, rgb.data())
+                                   : rtiow_host_write_ppm(name, precision, opt.width, opt.height, rgb.data());
+    if (wrc != 0) {
+        std::fprintf(stderr, "Error: Could not open file for writing: %s\n", name);
+        return -1;
+    }
+    const double t_write = lap();
+    rtiow_group_stats gs;
+    std::memset(&gs, 0, sizeof gs);
+    rtiow_group_get_stats(g, &gs);
+    const std::string note = rtiow_group_transport_note(g);
+    check_group(g, rtiow_group_destroy(g));
+    const double e2e_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - e2e_start).count();
+    std::printf("%15.8f\n", e2e_ms);
+    if (opt.stats) {
+        const double rays = (double)opt.width * opt.height * opt.samples;
+        std::string per;
+        for (int k = 0; k < n && k < RTIOW_GROUP_MAX_STATS; ++k) { char b[32]; std::snprintf(b, sizeof b, "%s%.6f", k ? ", " : "", gs.kernel_ms[k]); per += b; }
+        std::fprintf(stderr,
+                     "{\"mrays_per_s\": %.3f, \"render_ms\": %.6f, \"gpus\": %d, \"strip_rows\": %d, \"kernel_ms\": [%s], "
+                     "\"gather\": \"%s\", \"rccl_version\": %d, \"gather_ms\": %.6f, \"gather_bytes\": %llu, \"transport_note\": \"%s\", "
+                     "\"wall_ms\": {\"setup\": %.3f, \"rng_init\": %.3f, \"render\": %.3f, \"gather_and_readback\": %.3f, \"ppm_write\": %.3f, \"end_to_end\": %.3f}}\n",
+                     render_ms > 0 ? rays / render_ms / 1e3 : 0.0, (double)render_ms, n, strip_rows, per.c_str(),
+                     gs.gather_mode == RTIOW_GATHER_RCCL ? "rccl" : "peer", gs.rccl_version, gs.gather_ms, (unsigned long long)gs.gather_bytes, note.c_str(),
+                     t_setup, t_rng, t_render, t_read, t_write, e2e_ms);
+    }
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -125,6 +236,7 @@ int main(int argc, char** argv) {
         std::fputs(kUsage, stdout); std::fputs("\n", stdout);
         return 1;
     }
+    if (opt.gpus != 0 || !opt.devices.empty()) return main_multi_gpu(opt);
     const int precision = RTIOW_PRECISION;
     const size_t elem = precision == 64 ? 8 : 4;
 

@@ -162,7 +162,7 @@ template <class T> struct RenderParams {
     int local_rows, rank, nranks, strip_rows;
     int bx, by;                       // tile (block) shape in pixels
     int wave_tiles;                   // 1: lanes of a wave form 8x8 tiles inside the block
-    unsigned long long* seg_counter;  // COUNT variant only: total hit_world calls (path segments)
+    unsigned long long* seg_counter;  // COUNT variant only: [0] total hit_world calls (path segments) of this launch, [2] the longest per-pixel chain
     unsigned int* work_counter;       // SCHED_PERSISTENT: next unassigned pixel slot (zeroed per launch)
     int coop_offset;                  // SCHED_PERSISTENT: byte offset of the per-wave coop scratch in LDS
     // SCHED_SORTED (two phases of the persistent kernel): sample range of this launch, the
@@ -848,7 +848,7 @@ render_kernel(const RenderParams<T> p) {
             fresh = true;
         }
     }
-    if (COUNT) atomicAdd(p.seg_counter, (unsigned long long)nseg);
+    if (COUNT) { atomicAdd(p.seg_counter, (unsigned long long)nseg); atomicMax(p.seg_counter + 2, (unsigned long long)cost); }
     finish_pixel(p, lp, npix, st, cost);
 }
 
@@ -990,7 +990,11 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
             ++st.sample;
             st.depth = 0;
             if (st.sample < S) fresh = true;
-            else { PATH_STAT(PS_FINISH_PIXEL); finish_pixel(p, lp, npix, st, cost); alive = false; }
+            else {
+                PATH_STAT(PS_FINISH_PIXEL);
+                if (COUNT) atomicMax(p.seg_counter + 2, (unsigned long long)cost);   // a pixel's samples are ONE sequential chain: the frame cannot be shorter than the longest
+                finish_pixel(p, lp, npix, st, cost); alive = false;
+            }
         }
     }
     if (COUNT) {
@@ -1170,6 +1174,7 @@ struct rtiow_handle_s {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_a = nullptr, ev_b = nullptr;   // ev_a: prepass done, ev_b: main launch starts
     bool time_phases = false;
+    bool render_pending = false;                  // rtiow_render_async recorded its stop event, rtiow_render_wait has not read it yet
     std::string err;
 
     // scene
@@ -1204,7 +1209,8 @@ struct rtiow_handle_s {
     unsigned* sort_scratch = nullptr; size_t sort_scratch_bytes = 0;
     int waves_per_simd = 0;
     int num_cus = 256;
-    int last_count_blocks = 0;
+    int last_count_blocks = 0, last_count_waves_per_block = 0;
+    size_t timeline_cap_waves = 0;            // waves the debug timeline buffer holds
     unsigned int* work_counter = nullptr;
     unsigned long long* timeline = nullptr;   // debug: set only during rtiow_debug_timeline
     rtiow_stats stats{};
@@ -1224,6 +1230,16 @@ int fail(rtiow_handle_s* h, hipError_t e, const char* file, int line) {
 int fail_arg(rtiow_handle_s* h, int code, const char* msg) { if (h) h->err = msg; return code; }
 
 #define HIP_TRY(h, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail((h), e_, __FILE__, __LINE__); } while (0)
+
+// Device memory of one call: released on every return path (HIP_TRY returns early).
+struct DeviceScratch {
+    void* ptr = nullptr;
+    hipError_t alloc(size_t bytes) { return hipMalloc(&ptr, bytes); }
+    ~DeviceScratch() { if (ptr) (void)hipFree(ptr); }
+    DeviceScratch() = default;
+    DeviceScratch(const DeviceScratch&) = delete;
+    DeviceScratch& operator=(const DeviceScratch&) = delete;
+};
 
 int compute_local_rows(int H, int rank, int nranks, int strip_rows) {
     int rows = 0;
@@ -1415,7 +1431,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     size_t lds = lds_source ? sizeof(T) * 4 * (size_t)h->n_padded : 0;
     p.screen_offset = (int)lds;
     if (p.use_screen) lds += sizeof(float) * 4 * (size_t)h->n_padded;
-    p.timeline = seg_counter ? h->timeline : nullptr;
+    p.timeline = nullptr;                                    // set below, once the grid is known
     // shade records ride along in LDS while a workgroup's share stays within 1/5 of the CU's LDS
     const size_t coop_bytes = persistent ? (size_t)((threads + 63) / 64) * 64 * sizeof(CoopSlot<T>) : 0;
     const size_t shade_bytes = (sizeof(T) * 12 * (size_t)h->n + 15) / 16 * 16;
@@ -1530,10 +1546,15 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         p.cost_out = nullptr; p.order = nullptr; p.total_slots = 0; p.first_pools = 0; p.work_counter = nullptr;
     }
     if (prepare_only) return 0;
+    if (seg_counter) {
+        h->last_count_blocks = (int)(grid.x * grid.y);
+        h->last_count_waves_per_block = (threads + 63) / 64;
+        // the kernel writes 8 words per wave: hand the buffer over only if it holds every wave of this launch
+        if (h->timeline && (size_t)h->last_count_blocks * h->last_count_waves_per_block <= h->timeline_cap_waves) p.timeline = h->timeline;
+    }
     if (h->time_phases && phases == 2) HIP_TRY(h, hipEventRecord(h->ev_b, h->stream));
     hipLaunchKernelGGL(k, grid, block, lds, h->stream, p);
     HIP_TRY(h, hipGetLastError());
-    if (seg_counter) h->last_count_blocks = (int)(grid.x * grid.y);
     if (!seg_counter) {
         h->stats.vgprs = fa.numRegs;
         h->stats.sgprs = 0;
@@ -1727,16 +1748,18 @@ int rtiow_init_rng(rtiow_handle h, uint64_t seed) {
     return 0;
 }
 
-int rtiow_render(rtiow_handle h, int threads_per_block_row, float* kernel_ms) {
-    if (!h) return RTIOW_E_BADARG;
+namespace {
+// First half of rtiow_render: everything up to and including the stop event, nothing that blocks
+// the host (main.cu:334-339 without the synchronisation).
+int render_begin(rtiow_handle_s* h, int T, bool timed) {
     if (!h->have_camera || h->n == 0) return fail_arg(h, RTIOW_E_STATE, "rtiow_render before rtiow_set_scene/rtiow_set_camera");
     if (!h->rng_ready) return fail_arg(h, RTIOW_E_STATE, "rtiow_render before rtiow_init_rng");
-    const int T = threads_per_block_row;
     if (T < 0 || T > 32) return fail_arg(h, RTIOW_E_BADARG, "rtiow_render: threads_per_block_row must be 0..32");
     HIP_TRY(h, hipSetDevice(h->device));
     int rc = ensure_framebuffer(h);
     if (rc) return rc;
-    if (h->local_rows == 0) { if (kernel_ms) *kernel_ms = 0; return 0; }
+    h->render_pending = false;
+    if (h->local_rows == 0) { h->stats.render_ms = 0; h->stats.prepass_ms = 0; h->stats.main_ms = 0; return 0; }
     int bx, by, wave_tiles;
     block_shape(T, h->schedule == RTIOW_SCHED_STATIC, bx, by, wave_tiles);
     // allocations and table builds of a first render happen BEFORE the start event: the reference's
@@ -1744,29 +1767,66 @@ int rtiow_render(rtiow_handle h, int threads_per_block_row, float* kernel_ms) {
     if (h->precision == 32) rc = launch_render<float>(h, h->cam32, bx, by, wave_tiles, nullptr, true);
     else rc = launch_render<double>(h, h->cam64, bx, by, wave_tiles, nullptr, true);
     if (rc) return rc;
-    if (kernel_ms) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));                     // main.cu:334
-    h->time_phases = kernel_ms != nullptr;
+    if (timed) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));                         // main.cu:334
+    h->time_phases = timed;
     if (h->precision == 32) rc = launch_render<float>(h, h->cam32, bx, by, wave_tiles);
     else rc = launch_render<double>(h, h->cam64, bx, by, wave_tiles);
     h->time_phases = false;
     if (rc) return rc;
     const int S = h->precision == 32 ? h->cam32.samples_per_pixel : h->cam64.samples_per_pixel;
     h->stats.primary_rays = (uint64_t)h->local_rows * img_w(h) * (uint64_t)S;
-    if (kernel_ms) {
-        HIP_TRY(h, hipEventRecord(h->ev1, h->stream));                                // main.cu:339
-        HIP_TRY(h, hipEventSynchronize(h->ev1));                                      // main.cu:337,340
-        float ms = 0;
-        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-        *kernel_ms = ms;
-        h->stats.render_ms = ms;
-        h->stats.prepass_ms = 0; h->stats.main_ms = ms;
-        if (h->stats.phases == 2) {
-            float a = 0, b = 0;
-            HIP_TRY(h, hipEventElapsedTime(&a, h->ev0, h->ev_a));
-            HIP_TRY(h, hipEventElapsedTime(&b, h->ev_b, h->ev1));
-            h->stats.prepass_ms = a; h->stats.main_ms = b;
-        }
+    if (timed) { HIP_TRY(h, hipEventRecord(h->ev1, h->stream)); h->render_pending = true; }   // main.cu:339
+    return 0;
+}
+
+// Second half: wait for the stop event and read the event times (main.cu:337, 340-341).
+int render_wait(rtiow_handle_s* h, float* kernel_ms) {
+    if (!h->render_pending) { if (kernel_ms) *kernel_ms = (float)h->stats.render_ms; return 0; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    h->render_pending = false;
+    float ms = 0;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (kernel_ms) *kernel_ms = ms;
+    h->stats.render_ms = ms;
+    h->stats.prepass_ms = 0; h->stats.main_ms = ms;
+    if (h->stats.phases == 2) {
+        float a = 0, b = 0;
+        HIP_TRY(h, hipEventElapsedTime(&a, h->ev0, h->ev_a));
+        HIP_TRY(h, hipEventElapsedTime(&b, h->ev_b, h->ev1));
+        h->stats.prepass_ms = a; h->stats.main_ms = b;
     }
+    return 0;
+}
+}  // namespace
+
+int rtiow_render(rtiow_handle h, int threads_per_block_row, float* kernel_ms) {
+    if (!h) return RTIOW_E_BADARG;
+    int rc = render_begin(h, threads_per_block_row, kernel_ms != nullptr);
+    if (rc) return rc;
+    if (kernel_ms) { *kernel_ms = 0; return render_wait(h, kernel_ms); }
+    return 0;
+}
+
+int rtiow_render_async(rtiow_handle h, int threads_per_block_row) {
+    if (!h) return RTIOW_E_BADARG;
+    return render_begin(h, threads_per_block_row, true);
+}
+
+int rtiow_render_wait(rtiow_handle h, float* kernel_ms) {
+    if (!h) return RTIOW_E_BADARG;
+    return render_wait(h, kernel_ms);
+}
+
+int rtiow_stream(rtiow_handle h, void** hip_stream) {
+    if (!h || !hip_stream) return RTIOW_E_BADARG;
+    *hip_stream = (void*)h->stream;
+    return 0;
+}
+
+int rtiow_device(rtiow_handle h, int* device) {
+    if (!h || !device) return RTIOW_E_BADARG;
+    *device = h->device;
     return 0;
 }
 
@@ -1781,20 +1841,20 @@ int rtiow_count_segments(rtiow_handle h, int threads_per_block_row, uint64_t* se
     if (rc) return rc;
     *segments = 0;
     if (h->local_rows == 0) return 0;
-    unsigned long long* d = nullptr;                     // [0] prepass launch, [1] main (or only) launch
-    HIP_TRY(h, hipMalloc((void**)&d, 2 * sizeof *d));
-    HIP_TRY(h, hipMemsetAsync(d, 0, 2 * sizeof *d, h->stream));
+    DeviceScratch d;                                     // segments of [0] the prepass launch, [1] the main (or only) launch; [2], [3] their longest per-pixel chains; freed on every return path
+    HIP_TRY(h, d.alloc(4 * sizeof(unsigned long long)));
+    HIP_TRY(h, hipMemsetAsync(d.ptr, 0, 4 * sizeof(unsigned long long), h->stream));
     int bx, by, wave_tiles;
     block_shape(T, h->schedule == RTIOW_SCHED_STATIC, bx, by, wave_tiles);
-    if (h->precision == 32) rc = launch_render<float>(h, h->cam32, bx, by, wave_tiles, d);
-    else rc = launch_render<double>(h, h->cam64, bx, by, wave_tiles, d);
-    if (rc) { (void)hipFree(d); return rc; }
-    unsigned long long host[2] = {0, 0};
-    HIP_TRY(h, hipMemcpyAsync(host, d, sizeof host, hipMemcpyDeviceToHost, h->stream));
+    if (h->precision == 32) rc = launch_render<float>(h, h->cam32, bx, by, wave_tiles, (unsigned long long*)d.ptr);
+    else rc = launch_render<double>(h, h->cam64, bx, by, wave_tiles, (unsigned long long*)d.ptr);
+    if (rc) return rc;
+    unsigned long long host[4] = {0, 0, 0, 0};
+    HIP_TRY(h, hipMemcpyAsync(host, d.ptr, sizeof host, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    (void)hipFree(d);
     *segments = host[0] + host[1];
     h->stats.segments_prepass = host[0]; h->stats.segments_main = host[1];
+    h->stats.max_chain_prepass = host[2]; h->stats.max_chain_main = host[3];
     return 0;
 }
 
@@ -1873,22 +1933,26 @@ int rtiow_debug_timeline(rtiow_handle h, int threads_per_block_row, uint64_t* ou
     if (!h || !out_words || !waves) return RTIOW_E_BADARG;
     if (h->schedule == RTIOW_SCHED_STATIC) return fail_arg(h, RTIOW_E_STATE, "rtiow_debug_timeline needs a persistent schedule");
     HIP_TRY(h, hipSetDevice(h->device));
-    const size_t max_waves = 16384;
-    HIP_TRY(h, hipMalloc((void**)&h->timeline, max_waves * 8 * sizeof(unsigned long long)));
-    HIP_TRY(h, hipMemset(h->timeline, 0, max_waves * 8 * sizeof(unsigned long long)));
+    // a persistent launch never has more waves than the device holds (32 per CU); launch_render
+    // hands the buffer to the kernel only when it holds every wave of the launch
+    const size_t max_waves = (size_t)h->num_cus * 32;
+    DeviceScratch buf;
+    HIP_TRY(h, buf.alloc(max_waves * 8 * sizeof(unsigned long long)));
+    HIP_TRY(h, hipMemset(buf.ptr, 0, max_waves * 8 * sizeof(unsigned long long)));
+    h->timeline = (unsigned long long*)buf.ptr;
+    h->timeline_cap_waves = max_waves;
     uint64_t seg = 0;
     int rc = rtiow_count_segments(h, threads_per_block_row, &seg);
-    if (rc == 0) {
-        const int T = threads_per_block_row == 0 ? 16 : threads_per_block_row;
-        const size_t nw = (size_t)h->last_count_blocks * ((T * T + 63) / 64);
-        *waves = (int)nw;
-        const size_t words = nw * 8 < cap_words ? nw * 8 : cap_words;
-        hipError_t e = hipMemcpy(out_words, h->timeline, words * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(h, e, __FILE__, __LINE__);
-    }
-    (void)hipFree(h->timeline);
     h->timeline = nullptr;
-    return rc;
+    h->timeline_cap_waves = 0;
+    if (rc) return rc;
+    // the dynamic schedules launch four-wave workgroups whatever --threads says (block_shape)
+    const size_t nw = (size_t)h->last_count_blocks * (size_t)h->last_count_waves_per_block;
+    if (nw > max_waves) return fail_arg(h, RTIOW_E_STATE, "rtiow_debug_timeline: launch larger than the timeline buffer");
+    *waves = (int)nw;
+    const size_t words = nw * 8 < cap_words ? nw * 8 : cap_words;
+    HIP_TRY(h, hipMemcpy(out_words, buf.ptr, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
 }
 
 int rtiow_debug_jump_matrices(uint32_t* out_words, size_t cap_words, int from_scratch) {
@@ -1902,8 +1966,9 @@ int rtiow_debug_ops(rtiow_handle h, int op, size_t n, const void* a, const void*
     if (!h || !a || !out || n == 0) return RTIOW_E_BADARG;
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t es = elem_size(h), bytes = n * es;
-    void *da = nullptr, *db = nullptr, *dc = nullptr, *dout = nullptr;
-    HIP_TRY(h, hipMalloc(&da, bytes)); HIP_TRY(h, hipMalloc(&db, bytes)); HIP_TRY(h, hipMalloc(&dc, bytes)); HIP_TRY(h, hipMalloc(&dout, bytes));
+    DeviceScratch sa, sb, sc, sout;
+    HIP_TRY(h, sa.alloc(bytes)); HIP_TRY(h, sb.alloc(bytes)); HIP_TRY(h, sc.alloc(bytes)); HIP_TRY(h, sout.alloc(bytes));
+    void *da = sa.ptr, *db = sb.ptr, *dc = sc.ptr, *dout = sout.ptr;
     HIP_TRY(h, hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(db, b ? b : a, bytes, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(dc, c ? c : a, bytes, hipMemcpyHostToDevice));
@@ -1913,7 +1978,6 @@ int rtiow_debug_ops(rtiow_handle h, int op, size_t n, const void* a, const void*
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
-    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc); (void)hipFree(dout);
     return 0;
 }
 

@@ -25,11 +25,14 @@ class StripGather:
     """
 
     def __init__(self, width, height, rank, nranks, strip_rows=8, dtype=torch.float32, device="cpu", dst=0, group=None,
-                 stage_via_cpu=False):
+                 stage_via_cpu=False, always_collective=False):
         self.width, self.height, self.rank, self.nranks = width, height, rank, nranks
         self.strip_rows, self.dst, self.group = strip_rows, dst, group
         # rehearsal only: a gloo group cannot gather device tensors, so bounce through the host
         self.stage_via_cpu = stage_via_cpu and str(device) != "cpu"
+        # always_collective: run dist.gather even in a one-rank group (exercises the backend -- RCCL for
+        # device tensors -- on a one-GPU box; without it a lone rank just de-interleaves locally)
+        self.always_collective = always_collective
         self.rows = shard_rows(height, rank, nranks, strip_rows)
         self.pad_rows = max_local_rows(height, nranks, strip_rows)
         self.send = torch.zeros((self.pad_rows, width, 3), dtype=dtype, device=device)
@@ -46,7 +49,7 @@ class StripGather:
         return self.send[: len(self.rows)]
 
     def gather(self):
-        if self.nranks == 1:
+        if self.nranks == 1 and not self.always_collective:
             self.full.index_copy_(0, self.index[0], self.send[: len(self.rows)])
             return self.full
         if self.stage_via_cpu:

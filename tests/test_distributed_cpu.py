@@ -62,3 +62,22 @@ def test_strip_gather_single_rank(native):
     g = StripGather(8, 20, 0, 1, 8, torch.float32, "cpu")
     g.local_view().copy_(torch.arange(20 * 8 * 3, dtype=torch.float32).reshape(20, 8, 3))
     assert torch.equal(g.gather(), torch.arange(20 * 8 * 3, dtype=torch.float32).reshape(20, 8, 3))
+
+
+def _one_rank_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from raytracingincuda_amd.distributed import StripGather
+    g = StripGather(8, 20, 0, 1, 4, torch.float32, "cpu", always_collective=True)
+    g.local_view().copy_(torch.arange(20 * 8 * 3, dtype=torch.float32).reshape(20, 8, 3))
+    full = g.gather()                                   # dist.gather in a one-rank group (what bench.py does under torchrun at N=1)
+    np.save(out_path, full.numpy())
+    dist.destroy_process_group()
+
+
+def test_one_rank_group_still_runs_the_collective(tmp_path, native):
+    out = str(tmp_path / "one.npy")
+    mp.spawn(_one_rank_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    assert np.array_equal(np.load(out), np.arange(20 * 8 * 3, dtype=np.float32).reshape(20, 8, 3))

@@ -60,7 +60,7 @@ def _same_bits(a, b):
 def test_native_library_is_what_runs(rt):
     rt.load_host_library()
     with rt.Renderer(0, 32) as r:
-        assert r._lib.rtiow_abi_version() == 1
+        assert r._lib.rtiow_abi_version() == 2
     maps = open("/proc/self/maps").read()
     assert "librtiow_hip.so" in maps and "librtiow_host.so" in maps
 

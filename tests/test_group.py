@@ -1,0 +1,166 @@
+"""Single-process multi-GPU driver (rtiow_group_*, include/rtiow.h; raytracingincuda_amd/csrc/rtiow_group.hip).
+
+CPU part: the strip -> (rank, local row) mapping the device de-interleave kernel uses is the inverse of
+rtiow_set_shard's, and a group fails loudly without a GPU.  GPU part (-m gpu, one MI355X): `--gpus 1`
+goes through the group path and RCCL (a one-rank communicator: the rank sends its strips to itself, as
+ncclGather does for the root); several ranks mapped to the one device exercise sharding, the exchange
+by copies and the de-interleave; every assembled image equals the oracle's bit for bit.
+"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.conftest import compact
+
+
+def _same_bits(a, b):
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def test_deinterleave_mapping_is_the_inverse_of_the_shard_map(native):
+    """place_strips_kernel: global row j -> strip s = j / R, rank s % N, local row (s / N) * R + j % R."""
+    for H, N, R in [(1080, 8, 2), (1080, 8, 8), (37, 3, 4), (11, 5, 8), (192, 1, 8), (75, 4, 16), (9, 11, 1)]:
+        seen = np.zeros(H, bool)
+        for rank in range(N):
+            rows = native.shard_rows(H, rank, N, R)
+            for jl, j in enumerate(rows):
+                s = j // R
+                assert s % N == rank and (s // N) * R + j % R == jl, (H, N, R, rank, j)
+                seen[j] = True
+        assert seen.all()
+
+
+def test_group_without_gpu_fails_loudly(native):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(native.RtiowError):
+        native.RendererGroup(1, 32)
+    with pytest.raises(ValueError):
+        native.RendererGroup(2, 32, devices=[0])
+
+
+def _group_render(rt, prec, scene_id, W, H, S, B, n=1, devices=None, strip=8, gather=0, sched=2):
+    with rt.RendererGroup(n, prec, strip, gather, devices) as g:
+        g.set_camera(rt.camera(prec, W, H, S, B))
+        g.set_scene(rt.build_scene(scene_id, prec))
+        g.set_schedule(sched)
+        g.init_rng(1227)
+        ms = g.render(0)
+        img = g.read_framebuffer()
+        return img, ms, g.stats()
+
+
+@pytest.mark.gpu
+def test_group_of_one_goes_through_rccl(native, oracle):
+    rt = native
+    W, H, S, B = 160, 96, 6, 25
+    want, _ = oracle.render(32, compact(oracle.build_scene(3, 32)), rt.camera(32, W, H, S, B), 1227)
+    img, ms, st = _group_render(rt, 32, 3, W, H, S, B, n=1, gather=rt.GATHER_RCCL)
+    assert _same_bits(img, want)
+    assert st["gather_mode"] == rt.GATHER_RCCL and st["rccl_version"] > 0 and st["transport_note"] == ""
+    assert st["ngpus"] == 1 and ms > 0 and abs(st["kernel_ms"][0] - ms) < 1e-6 and st["gather_ms"] > 0
+    assert st["gather_bytes"] == W * H * 12
+    # auto picks RCCL too when it is there; fp64
+    want64, _ = oracle.render(64, compact(oracle.build_scene(2, 64)), rt.camera(64, 80, 48, 3, 25), 1227)
+    img64, _, st64 = _group_render(rt, 64, 2, 80, 48, 3, 25, n=1)
+    assert _same_bits(img64, want64) and st64["gather_mode"] == rt.GATHER_RCCL and st64["gather_bytes"] == 80 * 48 * 24
+
+
+@pytest.mark.gpu
+def test_group_ranks_sharing_one_device_assemble_the_single_gpu_image(native, oracle):
+    rt = native
+    W, H, S, B = 96, 75, 3, 10
+    want, _ = oracle.render(32, compact(oracle.build_scene(3, 32)), rt.camera(32, W, H, S, B), 1227)
+    for n, strip in [(2, 8), (3, 8), (8, 2), (4, 16), (5, 1), (16, 8)]:
+        img, ms, st = _group_render(rt, 32, 3, W, H, S, B, n=n, devices=[0] * n, strip=strip)
+        assert _same_bits(img, want), (n, strip)
+        assert st["gather_mode"] == rt.GATHER_PEER and "distinct devices" in st["transport_note"]
+        assert len(st["kernel_ms"]) == min(n, 16) and max(st["kernel_ms"]) == pytest.approx(st["kernel_ms_max"]) and ms == pytest.approx(st["kernel_ms_max"])
+    want64, _ = oracle.render(64, compact(oracle.build_scene(1, 64)), rt.camera(64, 64, 40, 2, 25), 1227)
+    img64, _, _ = _group_render(rt, 64, 1, 64, 40, 2, 25, n=3, devices=[0, 0, 0], strip=4, gather=rt.GATHER_PEER)
+    assert _same_bits(img64, want64)
+    # RCCL cannot serve ranks that share a device: asking for it explicitly fails with the reason
+    with pytest.raises(rt.RtiowError) as e:
+        _group_render(rt, 32, 3, 32, 16, 1, 2, n=2, devices=[0, 0], gather=rt.GATHER_RCCL)
+    assert "RCCL" in str(e.value)
+    # a group asked for more devices than are visible fails at creation
+    import torch
+    with pytest.raises(rt.RtiowError):
+        rt.RendererGroup(torch.cuda.device_count() + 1, 32)
+
+
+@pytest.mark.gpu
+def test_group_matches_single_handle_at_headline_geometry(native):
+    """Scene 3, 1920x1080 (20 spp to keep it short): 8 ranks on the one device, 2-row strips, against the
+    plain single-handle render; render twice through one group (buffers and communicator are reused)."""
+    rt = native
+    W, H, S, B = 1920, 1080, 20, 50
+    with rt.Renderer(0, 32) as r:
+        r.set_camera(rt.camera(32, W, H, S, B)); r.set_scene(rt.build_scene(3, 32)); r.init_rng(1227)
+        r.render(0)
+        want = r.read_framebuffer()
+    with rt.RendererGroup(8, 32, 2, rt.GATHER_AUTO, [0] * 8) as g:
+        g.set_camera(rt.camera(32, W, H, S, B)); g.set_scene(rt.build_scene(3, 32)); g.init_rng(1227)
+        g.render(0)
+        a = g.read_framebuffer()
+        g.render(8)
+        b = g.read_framebuffer()
+        assert g.stats()["gather_bytes"] == W * H * 12
+    assert _same_bits(a, want) and _same_bits(b, want)
+    img, _, st = _group_render(rt, 32, 3, W, H, S, B, n=1)
+    assert _same_bits(img, want) and st["gather_mode"] == rt.GATHER_RCCL
+
+
+@pytest.mark.gpu
+def test_executable_gpus_flag(native, oracle, tmp_path):
+    """--gpus 1 (group path, RCCL) and --devices 0,0,0 (three ranks on the one GPU, copies): same stdout
+    format, same file name, same P3 bytes as the single-handle path and as the oracle."""
+    rt = native
+    exe = os.path.join(os.path.dirname(rt.lib_paths()["hip"]), "..", "bin", "global-float-hip-raytrace")
+    base = ["--scene_id", "1", "--width=160", "--height", "96", "--samples", "4", "--bounces=25", "--threads", "8"]
+    name = "global_float_scene1_160x96_4samples_25bounces_8threadsPerBlockRow.ppm"
+    want, _ = oracle.render(32, compact(oracle.build_scene(1, 32)), rt.camera(32, 160, 96, 4, 25), 1227)
+    for extra, transport in ((["--gpus", "1"], "rccl"), (["--devices", "0,0,0"], "peer"), (["--gpus=2", "--devices=0,0", "--gather", "peer", "--strip_rows", "4"], "peer")):
+        d = tmp_path / ("run_" + "_".join(x.strip("-").replace(",", "") for x in extra)); d.mkdir()
+        r = subprocess.run([exe] + base + extra + ["--stats"], capture_output=True, text=True, cwd=str(d))
+        assert r.returncode == 0, r.stderr
+        assert len(r.stdout) == 32 and r.stdout.count(",") == 1
+        render_ms, e2e_ms = (float(x) for x in r.stdout.split(","))
+        assert 0 < render_ms < e2e_ms
+        assert open(str(d / name), "rb").read() == rt.format_ppm(want), extra
+        st = json.loads(r.stderr.strip().splitlines()[-1])
+        assert st["gather"] == transport and st["gather_bytes"] == 160 * 96 * 12 and len(st["kernel_ms"]) == st["gpus"]
+        assert max(st["kernel_ms"]) == pytest.approx(render_ms, abs=1e-5)
+    # more GPUs than the box has: the reference's error convention (message on stderr, non-zero exit, empty stdout)
+    import torch
+    r = subprocess.run([exe] + base + ["--gpus", str(torch.cuda.device_count() + 1)], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode != 0 and r.stdout == "" and "HIP_SAFE_CALL" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_runs_rccl_at_world_size_one(native):
+    """bench.py launched the way the driver launches N>1 runs, with one rank: process group "nccl" (RCCL),
+    the strip gather, the all_reduce / all_gather of the timings and the barriers all execute on hardware."""
+    import socket
+    import sys
+    from tests.conftest import ROOT
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--width", "256", "--height", "144", "--samples", "64", "--bounces", "10", "--no-cpu-baseline"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl" and "strips" in d["config"]["sharding"]
+    sd = d["scaling_detail"]
+    assert sd["gather_ms"] is not None and sd["gather_ms"] > 0 and sd["gather_bytes_total"] == 256 * 144 * 12
+    assert len(sd["kernel_ms_per_rank"]) == 1 and len(sd["gather_ms_per_rank"]) == 1
+    assert 0 < sd["floor_ms"] <= d["ms_per_step"] and sd["longest_chain_segments"] > 64 and 0.3 < sd["lone_ray_trip_us"] < 50
