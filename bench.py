@@ -153,6 +153,11 @@ def lone_ray_trip_us(rt, device_index, prec, scene, args):
 
 def main():
     args = parse()
+    # The driver reads ONE JSON line from stdout; libraries are chatty there (RCCL prints a version
+    # banner on stdout when its first communicator is created).  Everything but that line goes to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -315,7 +320,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
             line["cpu_baseline"]["config1"] = cpu_baseline_config1()
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     r.close()
     if distributed:
         dist.barrier()

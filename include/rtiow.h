@@ -230,7 +230,10 @@ typedef struct {
 /* devices == NULL: devices 0..ngpus-1.  A device may be listed more than once (ranks then share
  * it and the exchange uses copies: RCCL needs distinct devices) -- used to test the N-rank logic
  * on a one-GPU box. */
+/* The transport is chosen and the RCCL communicator created here (seconds: keep it out of timed
+ * regions); RTIOW_GATHER_RCCL fails here (RTIOW_E_STATE) when RCCL cannot serve the group. */
 int rtiow_group_create(int ngpus, const int* devices, int precision, int strip_rows, int gather, rtiow_group* out);
+const char* rtiow_group_create_error(void);   /* text for the last failed rtiow_group_create of this process */
 int rtiow_group_destroy(rtiow_group g);
 const char* rtiow_group_last_error_string(rtiow_group g);
 int rtiow_group_size(rtiow_group g);

@@ -82,7 +82,7 @@ HIP_SYMBOLS = [
     "rtiow_read_framebuffer", "rtiow_set_scene_source", "rtiow_set_schedule", "rtiow_get_stats", "rtiow_synchronize",
     "rtiow_debug_read_rng", "rtiow_debug_timeline", "rtiow_debug_ops", "rtiow_debug_jump_matrices",
     "rtiow_render_async", "rtiow_render_wait", "rtiow_stream", "rtiow_device",
-    "rtiow_group_create", "rtiow_group_destroy", "rtiow_group_last_error_string", "rtiow_group_size", "rtiow_group_member",
+    "rtiow_group_create", "rtiow_group_create_error", "rtiow_group_destroy", "rtiow_group_last_error_string", "rtiow_group_size", "rtiow_group_member",
     "rtiow_group_set_scene", "rtiow_group_set_camera", "rtiow_group_set_scene_source", "rtiow_group_set_schedule",
     "rtiow_group_init_rng", "rtiow_group_render", "rtiow_group_gather", "rtiow_group_framebuffer_device_ptr",
     "rtiow_group_read_framebuffer", "rtiow_group_get_stats", "rtiow_group_transport_note",
@@ -164,6 +164,8 @@ def load_hip_library():
         lib.rtiow_device.argtypes = [H, ctypes.POINTER(ctypes.c_int)]
         G = ctypes.c_void_p
         lib.rtiow_group_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(G)]
+        lib.rtiow_group_create_error.argtypes = []
+        lib.rtiow_group_create_error.restype = ctypes.c_char_p
         lib.rtiow_group_destroy.argtypes = [G]
         lib.rtiow_group_last_error_string.argtypes = [G]
         lib.rtiow_group_last_error_string.restype = ctypes.c_char_p
@@ -454,7 +456,8 @@ class RendererGroup:
         rc = self._lib.rtiow_group_create(self.ngpus, devs, int(precision), int(strip_rows), int(gather), ctypes.byref(self._g))
         if rc:
             self._g = None
-            raise RtiowError(rc, "rtiow_group_create(%d GPUs) failed -- are that many GPUs visible?" % self.ngpus)
+            why = self._lib.rtiow_group_create_error().decode(errors="replace")
+            raise RtiowError(rc, "rtiow_group_create(%d GPUs) failed: %s" % (self.ngpus, why or "are that many GPUs visible?"))
         self.width = self.height = 0
 
     def _check(self, rc):

@@ -162,7 +162,7 @@ int main_multi_gpu(const Options& opt) {
     const int strip_rows = opt.strip_rows > 0 ? opt.strip_rows : (n <= 2 ? 8 : 2);
     rtiow_group g = nullptr;
     int rc = rtiow_group_create(n, opt.devices.empty() ? nullptr : opt.devices.data(), precision, strip_rows, opt.gather, &g);   // main.cu:81-92, per device
-    if (rc) { std::fprintf(stderr, "HIP_SAFE_CALL: cannot open %d device(s) (error %d)\n", n, rc); return rc; }
+    if (rc) { std::fprintf(stderr, "HIP_SAFE_CALL: cannot open %d device(s) (error %d) %s\n", n, rc, rtiow_group_create_error()); return rc; }
     const auto e2e_start = std::chrono::steady_clock::now();                 // main.cu:95
     auto lap = [last = e2e_start]() mutable {
         const auto now = std::chrono::steady_clock::now();

@@ -27,6 +27,7 @@
 #include <rccl/rccl.h>   // types and prototypes only; every call goes through dlsym'ed pointers
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdint>
@@ -133,6 +134,15 @@ int gfail_member(rtiow_group_s* g, int k, int rc) {
 #define G_HIP(g, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return gfail_hip((g), e_, __FILE__, __LINE__); } while (0)
 #define G_EACH(g, call) do { for (int k_ = 0; k_ < (g)->n; ++k_) { rtiow_handle hk = (g)->h[(size_t)k_]; int rc_ = (call); if (rc_) return gfail_member((g), k_, rc_); } } while (0)
 
+// RCCL prints a version banner on STDOUT when its first communicator is created ("RCCL version :
+// ... Librccl path : ..."), and stdout is the reference's CSV fragment (main.cu:342-343, 397-398):
+// while RCCL initialises, file descriptor 1 points at stderr.
+struct StdoutToStderr {
+    int saved = -1;
+    StdoutToStderr() { std::fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
+    ~StdoutToStderr() { std::fflush(stdout); if (saved >= 0) { dup2(saved, 1); close(saved); } }
+};
+
 bool distinct_devices(const rtiow_group_s* g) {
     std::vector<int> d = g->dev;
     std::sort(d.begin(), d.end());
@@ -149,7 +159,8 @@ int resolve_transport(rtiow_group_s* g) {
     if (ok && !g->rccl.load(why)) ok = false;
     if (ok) {
         g->comms.assign((size_t)g->n, nullptr);
-        const ncclResult_t r = g->rccl.CommInitAll(g->comms.data(), g->n, g->dev.data());
+        ncclResult_t r;
+        { StdoutToStderr quiet; r = g->rccl.CommInitAll(g->comms.data(), g->n, g->dev.data()); }
         if (r != ncclSuccess) {
             ok = false;
             why = std::string("ncclCommInitAll: ") + g->rccl.GetErrorString(r);
@@ -207,7 +218,11 @@ int ensure_group_buffers(rtiow_group_s* g) {
 
 }  // namespace
 
+namespace { std::string g_create_error; }   // why the last rtiow_group_create of this process failed
+
 extern "C" {
+
+const char* rtiow_group_create_error(void) { return g_create_error.c_str(); }
 
 int rtiow_group_create(int ngpus, const int* devices, int precision, int strip_rows, int gather, rtiow_group* out) {
     if (!out) return RTIOW_E_BADARG;
@@ -238,8 +253,18 @@ int rtiow_group_create(int ngpus, const int* devices, int precision, int strip_r
         if (rc == 0) rc = (int)hipEventCreate(&g->g0);
         if (rc == 0) rc = (int)hipEventCreate(&g->g1);
     }
-    if (rc) { rtiow_group_destroy(g); return rc; }
+    // The communicator is created HERE, with the devices' contexts (the reference's cudaSetDevice /
+    // event creation, main.cu:81-92, before its end-to-end timer starts): ncclCommInitAll takes
+    // seconds (topology discovery), the exchange itself microseconds.
+    if (rc == 0) rc = resolve_transport(g);
+    if (rc) {
+        g_create_error = g->err.empty() ? "rtiow_group_create: device or stream creation failed (error " + std::to_string(rc) + ")" : g->err;
+        rtiow_group_destroy(g);
+        return rc;
+    }
+    g_create_error.clear();
     g->stats.ngpus = ngpus; g->stats.strip_rows = strip_rows;
+    g->stats.gather_mode = g->gather_mode; g->stats.rccl_version = g->rccl_version;
     *out = g;
     return 0;
 }
