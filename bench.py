@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--bounces", type=int, default=50)
     ap.add_argument("--precision", type=int, default=32, choices=(32, 64))
     ap.add_argument("--threads", type=int, default=0, help="reference --threads (block T x T); 0 = library tiling")
-    ap.add_argument("--scene_source", default="lds", choices=("lds", "scalar"))
+    ap.add_argument("--scene_source", default="grid", choices=("grid", "lds", "scalar", "lds_exact"))
     ap.add_argument("--schedule", default="sorted", choices=("sorted", "persistent", "static"))
     ap.add_argument("--strip_rows", type=int, default=0, help="rows per interleaved strip; 0 = 8 for N <= 2, 2 for N >= 4 (profiles/r01_strip_rows_sweep.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -197,7 +197,7 @@ def main():
     r.set_stream(stream.cuda_stream)
     r.set_camera(cam)
     r.set_scene(scene)
-    r.set_scene_source(rt.SCENE_LDS if args.scene_source == "lds" else rt.SCENE_SCALAR)
+    r.set_scene_source({"grid": rt.SCENE_GRID, "lds": rt.SCENE_LDS, "scalar": rt.SCENE_SCALAR, "lds_exact": rt.SCENE_LDS_EXACT}[args.scene_source])
     r.set_schedule({"sorted": rt.SCHED_SORTED, "persistent": rt.SCHED_PERSISTENT, "static": rt.SCHED_STATIC}[args.schedule])
     r.set_shard(rank, world, args.strip_rows)
     gather = StripGather(W, H, rank, world, args.strip_rows, tdtype, "cuda:%d" % device_index, stage_via_cpu=(backend != "nccl"),

@@ -40,11 +40,15 @@ extern "C" {
 
 /* Scene-table source selected for the sphere loop (the AMD analogue of the reference's
  * global / constant / texture variants, README.md:7-12). */
-#define RTIOW_SCENE_LDS       0 /* sphere list staged into LDS per workgroup (default), with the packed-
+#define RTIOW_SCENE_LDS       0 /* sphere list staged into LDS per workgroup, with the packed-
                                  * fp32 8-operation conservative screen in front of the exact test
                                  * (both precisions)                                             */
 #define RTIOW_SCENE_SCALAR    1 /* wave-uniform scalar loads through the scalar cache, exact loop */
 #define RTIOW_SCENE_LDS_EXACT 2 /* LDS, the reference's 12-operation test on every sphere        */
+#define RTIOW_SCENE_GRID      3 /* default: LDS tables plus a uniform grid over the small spheres -- a
+                                 * lane walks the cells its ray crosses and tests only their spheres,
+                                 * exactly; big spheres are tested by every ray.  Same image bit for
+                                 * bit.  Scenes the grid does not suit run as RTIOW_SCENE_LDS.     */
 
 /* Pixel scheduling (same image either way):
  * STATIC     = the reference's launch geometry: grid of T x T blocks, one lane per pixel

@@ -21,7 +21,7 @@ import os
 import numpy as np
 
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
-SCENE_LDS, SCENE_SCALAR, SCENE_LDS_EXACT = 0, 1, 2
+SCENE_LDS, SCENE_SCALAR, SCENE_LDS_EXACT, SCENE_GRID = 0, 1, 2, 3
 SCHED_STATIC, SCHED_PERSISTENT, SCHED_SORTED = 0, 1, 2
 GATHER_AUTO, GATHER_RCCL, GATHER_PEER = 0, 1, 2
 GROUP_MAX_STATS = 16

@@ -26,7 +26,7 @@ namespace {
 struct Options {
     bool have_scene = false, help = false;
     int scene_id = 0, width = 320, height = 192, samples = 10, bounces = 25, threads = 8;   // main.cu:45-54
-    int scene_source = RTIOW_SCENE_LDS;
+    int scene_source = RTIOW_SCENE_GRID;
     bool stats = false;
     bool binary_ppm = false;
     int schedule = RTIOW_SCHED_SORTED;
@@ -87,7 +87,8 @@ Options parse(int argc, char** argv) {
             value = argv[++k];
         }
         if (name == "scene_source") {
-            if (value == "lds") o.scene_source = RTIOW_SCENE_LDS;
+            if (value == "grid") o.scene_source = RTIOW_SCENE_GRID;
+            else if (value == "lds") o.scene_source = RTIOW_SCENE_LDS;
             else if (value == "scalar") o.scene_source = RTIOW_SCENE_SCALAR;
             else parse_abort("Argument '" + value + "' failed to parse");
             continue;
@@ -310,7 +311,7 @@ int main(int argc, char** argv) {
                      "\"vgprs\": %d, \"lds_bytes\": %d, \"scene_source\": \"%s\", "
                      "\"wall_ms\": {\"setup\": %.3f, \"rng_init\": %.3f, \"render\": %.3f, \"readback\": %.3f, \"ppm_write\": %.3f, \"end_to_end\": %.3f}}\n",
                      render_ms > 0 ? rays / render_ms / 1e3 : 0.0, (double)render_ms, st.rng_init_ms, st.num_spheres,
-                     st.block_x, st.block_y, st.vgprs, st.lds_bytes, st.scene_source == RTIOW_SCENE_LDS ? "lds" : "scalar",
+                     st.block_x, st.block_y, st.vgprs, st.lds_bytes, st.scene_source == RTIOW_SCENE_GRID ? "grid" : (st.scene_source == RTIOW_SCENE_SCALAR ? "scalar" : "lds"),
                      t_setup, t_rng, t_render, t_read, t_write, e2e_ms);
     }
     return 0;

@@ -139,9 +139,59 @@ rng_init_kernel(uint32_t* __restrict__ states, const uint32_t* __restrict__ jump
 // =====================================================================================
 template <class T> struct V3 { T x, y, z; };
 
-template <class T> struct RenderParams {
-    int W, H, S, B;
+// Uniform grid over the small spheres of the scene (hit_world_grid).  x/z run over the cells, the
+// y extent of the gridded spheres is one slab.  All coordinates are fp32 and relative to nothing:
+// x0/z0 are subtracted by the kernel.  Offsets are bytes from the start of dynamic LDS.
+struct GridParams {
+    int use_grid;
+    int nx, nz;
+    float x0, z0, cell, inv_cell;     // cell (ix, iz) covers [x0 + ix*cell, x0 + (ix+1)*cell) x [z0 + iz*cell, ...)
+    float ylo, yhi;                   // slab of the registered (inflated) spheres
+    float far2;                       // |O - ctr|^2 above this: the per-sphere registration margin no longer covers the reference's rounding noise
+    float core_lo[3], core_hi[3];     // box of the gridded spheres' CENTRES (far rays are clipped against it, inflated per ray)
+    float rmax2, cmax;                // largest gridded radius squared; largest |C - ctr| over the gridded spheres
+    int n_direct_padded;              // spheres every ray tests exactly (too big for a cell, or the overflow of a full cell), padded to x4
+    int cells_offset, aos_offset, direct_offset, direct_ids_offset;
+    const unsigned char* __restrict__ blob;   // cells | aos | direct table | direct ids, as laid out in LDS from cells_offset on
+    int blob_bytes;
+};
+
+// Launch parameters, split by how often the kernel needs them.  The HOT part (camera, table
+// offsets, loop bounds) stays in SGPRs for the whole kernel.  The COLD part (buffer pointers, image
+// and shard geometry, sort hand-over) is needed only when a lane takes a new pixel or finishes one:
+// it is read with scalar loads from the kernarg segment at those sites (cold_of), so it does not
+// occupy ~35 SGPRs during the path loop (the all-by-value form spilled 45 SGPRs to VGPR lanes, with
+// 75 v_readlane/v_writelane moves inside the loop).
+template <class T> struct ColdParams {
+    int W, H, S;
     T pixel_samples_scale;
+    const uint32_t* __restrict__ rng; // [6][npix_local] SoA
+    T* __restrict__ fb;               // [local_rows][W][3]
+    int local_rows, rank, nranks, strip_rows;
+    int bx, by;                       // tile (block) shape in pixels (static schedule)
+    int wave_tiles;                   // 1: lanes of a wave form 8x8 tiles inside the block
+    unsigned long long* seg_counter;  // COUNT variant only: [0] total hit_world calls (path segments) of this launch, [2] the longest per-pixel chain
+    unsigned int* work_counter;       // SCHED_PERSISTENT: next unassigned pixel slot (zeroed per launch)
+    // SCHED_SORTED (two phases of the persistent kernel): first sample of this launch, the
+    // per-pixel state carried between the phases, and the cost-sorted hand-out order.
+    int s_begin;                      // samples [s_begin, s_end) of every pixel
+    const uint32_t* __restrict__ rng_in;   // [6][npix] SoA state at sample s_begin
+    // SCHED_SORTED hand-over between the prepass and the main launch: ONE record per pixel
+    // (MidState<T>: RNG state after sample s_end-1 + colour sum), so that the main launch, which
+    // visits the pixels in cost order, fetches one or two cache lines per pixel instead of nine
+    // (SoA cost 630 MB of fetches per frame for 83 MB of state).
+    const unsigned char* __restrict__ mid_in;   // main launch: state at sample s_begin (nullptr: rng_in, zero sum)
+    unsigned char* __restrict__ mid_out;        // prepass: park the state (nullptr: final launch, the pixel is stored)
+    uint32_t* __restrict__ cost_out;  // prepass only: segments the pixel ran in this launch
+    const int* __restrict__ order;    // slot -> local pixel (or -1), nullptr: 8x8 tiles bottom-up
+    int total_slots;
+    int first_pools;                  // 1: wave w starts with pool w (the work counter then starts at the wave count)
+    unsigned long long* timeline;     // COUNT variant, optional: per wave {t_start, t_exhausted, t_end, iters_normal, iters_coop, pixels, 0, 0}
+};
+
+template <class T> struct RenderParams {
+    int B, s_end;                     // bounce limit; this launch renders samples [cold.s_begin, s_end)
+    int lane_cap;                     // lanes of a wave that take pixels (64; fewer when the launch is underfilled, see launch_render)
     V3<T> center, pixel00, du, dv;
     T defocus_angle;
     V3<T> ddu, ddv;
@@ -157,31 +207,21 @@ template <class T> struct RenderParams {
     const T* __restrict__ shade_tbl;
     int shade_in_lds;                 // 1: the table is staged behind the loop table in LDS (shade_offset bytes)
     int shade_offset;
-    const uint32_t* __restrict__ rng; // [6][npix_local] SoA
-    T* __restrict__ fb;               // [local_rows][W][3]
-    int local_rows, rank, nranks, strip_rows;
-    int bx, by;                       // tile (block) shape in pixels
-    int wave_tiles;                   // 1: lanes of a wave form 8x8 tiles inside the block
-    unsigned long long* seg_counter;  // COUNT variant only: [0] total hit_world calls (path segments) of this launch, [2] the longest per-pixel chain
-    unsigned int* work_counter;       // SCHED_PERSISTENT: next unassigned pixel slot (zeroed per launch)
     int coop_offset;                  // SCHED_PERSISTENT: byte offset of the per-wave coop scratch in LDS
-    // SCHED_SORTED (two phases of the persistent kernel): sample range of this launch, the
-    // per-pixel state carried between the phases, and the cost-sorted hand-out order.
-    int s_begin, s_end;               // samples [s_begin, s_end) of every pixel
-    const uint32_t* __restrict__ rng_in;   // [6][npix] SoA state at sample s_begin
-    // SCHED_SORTED hand-over between the prepass and the main launch: ONE record per pixel
-    // (MidState<T>: RNG state after sample s_end-1 + colour sum), so that the main launch, which
-    // visits the pixels in cost order, fetches one or two cache lines per pixel instead of nine
-    // (SoA cost 630 MB of fetches per frame for 83 MB of state).
-    const unsigned char* __restrict__ mid_in;   // main launch: state at sample s_begin (nullptr: rng_in, zero sum)
-    unsigned char* __restrict__ mid_out;        // prepass: park the state (nullptr: final launch, the pixel is stored)
-    uint32_t* __restrict__ cost_out;  // prepass only: segments the pixel ran in this launch
-    const int* __restrict__ order;    // slot -> local pixel (or -1), nullptr: 8x8 tiles bottom-up
-    int total_slots;
-    int first_pools;                  // 1: wave w starts with pool w (the work counter then starts at the wave count)
-    int lane_cap;                     // lanes of a wave that take pixels (64; fewer when the launch is underfilled, see launch_render)
-    unsigned long long* timeline;     // COUNT variant, optional: per wave {t_start, t_exhausted, t_end, iters_normal, iters_coop, pixels, 0, 0}
+    GridParams grid;                  // RTIOW_SCENE_GRID: uniform grid over the small spheres (use_grid != 0)
+    ColdParams<T> cold;
 };
+
+// The cold half of the kernel's own argument, re-read from the kernarg segment.  The empty asm
+// makes the base pointer opaque at every call site, so the scalar loads stay inside the (rare)
+// block that needs them instead of being hoisted to the kernel entry and kept live.
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(4))) ColdParams<T>& cold_of(const RenderParams<T>&) {
+    typedef const __attribute__((address_space(4))) char* kptr;
+    kptr k = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return *(const __attribute__((address_space(4))) ColdParams<T>*)(k + offsetof(RenderParams<T>, cold));
+}
 
 #define RT_FMA(a, b, c) Real<T>::fma((a), (b), (c))
 
@@ -207,7 +247,7 @@ template <class T> __device__ __forceinline__ V3<T> reflect3(V3<T> v, V3<T> n) {
 // is the time budget (scripts/path_stats_probe.py).  Compiled out by default.
 #ifdef RTIOW_PATH_STATS
 enum { PS_ITERATION = 0, PS_RUV_CALL, PS_RUV_ROUND, PS_DISK_ROUND, PS_GEN_PRIMARY, PS_SHADE_HIT, PS_SKY, PS_DIELECTRIC, PS_METAL,
-       PS_EXACT_BLOCK, PS_FINISH_CALL, PS_IEEE_BLOCK, PS_SECOND_DIV, PS_SCHLICK_DRAW, PS_REFILL, PS_FINISH_PIXEL, PS_COUNT };
+       PS_EXACT_BLOCK, PS_FINISH_CALL, PS_IEEE_BLOCK, PS_SECOND_DIV, PS_SCHLICK_DRAW, PS_REFILL, PS_FINISH_PIXEL, PS_GRID_STEP, PS_COUNT };
 __device__ unsigned long long g_path_stats[2 * PS_COUNT];
 __device__ __forceinline__ void path_stat(int region) {
     const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
@@ -287,7 +327,12 @@ __device__ __forceinline__ double fast_sqrt(double x) { return __builtin_amdgcn_
 // discriminant to zero).  Rays leaving the ground sphere (|h|, sqrt ~ 1000, far root = rounding
 // noise ~1e-4) are what the tight bound is for: with 2^-20 every one of them fell through to
 // the IEEE code.  In doubt the exact code runs, so the result is unchanged.
-template <class T>
+//
+// ANYORDER: the caller does not visit the spheres in index order (hit_world_grid).  The reference's
+// loop keeps the FIRST sphere among equal roots (`root < closest_so_far` is strict, hittable.h:54-56),
+// i.e. its result is the lexicographic minimum of (t, index); out of order that is `root < closest,
+// or root == closest and a lower index`.  Testing a sphere twice changes nothing.
+template <class T, bool ANYORDER = false>
 __device__ __forceinline__ void finish_sphere_test(int s, T h, T disc, T a, T& closest, int& hit) {
     const T tmin = (T)0.001;
     PATH_STAT(PS_FINISH_CALL);
@@ -303,11 +348,15 @@ __device__ __forceinline__ void finish_sphere_test(int s, T h, T disc, T a, T& c
     PATH_STAT(PS_IEEE_BLOCK);
     const T sq = Real<T>::sqrt(disc);                               // :50
     T root = (h - sq) / a;                                          // :53
-    bool ok = (tmin < root) && (root < closest);                    // :54
+    auto inside = [&](T r) {
+        if (ANYORDER) return (tmin < r) && (r < closest || (r == closest && (unsigned)s < (unsigned)hit));
+        return (tmin < r) && (r < closest);
+    };
+    bool ok = inside(root);                                         // :54
     if (!ok) {
         PATH_STAT(PS_SECOND_DIV);
         root = (h + sq) / a;                                        // :55
-        ok = (tmin < root) && (root < closest);                     // :56
+        ok = inside(root);                                          // :56
     }
     if (ok) { closest = root; hit = s; }                            // hittable.h:88-92
 }
@@ -494,6 +543,180 @@ __device__ __forceinline__ void hit_world_screened(const RenderParams<T>& p, con
     }
 }
 
+// =====================================================================================
+// hit_world over a uniform grid (RTIOW_SCENE_GRID, the default).
+//
+// The screen above still costs every ray 8 operations per sphere.  The host therefore also bins
+// the SMALL spheres of the scene into a 2-D grid of cells over x/z (one slab in y), at most four
+// per cell (build_grid_tables); a lane walks only the cells its own ray crosses while it is inside
+// the slab and tests their spheres with the reference's exact arithmetic.  Spheres that do not fit
+// a cell (the ground, the three unit spheres) or overflow a full one form the DIRECT list, which
+// every ray tests exactly in packed trips first.  Measured on the headline scene a wave walks 1.7
+// cells per iteration (its longest lane) instead of screening 125 spheres.
+//
+// Why the result is unchanged.  The reference's nearest hit is the lexicographic minimum of
+// (t, index) over the spheres whose hit_sphere succeeds; a sphere's own candidate root does not
+// depend on the others (finish_sphere_test).  It therefore suffices that every sphere the
+// reference COULD accept is tested, with the reference's arithmetic and the ANYORDER tie rule:
+//  * hit_sphere can only succeed if its computed discriminant is >= 0, and that discriminant
+//    differs from the real-number one by at most E = 18u(|oc|^2 + r^2) (u = 2^-24),
+//    so the ray's LINE passes within sqrt(r^2 + E) of the centre, and the point at the accepted
+//    root lies inside that inflated ball (its squared distance from the centre is r^2 + (computed
+//    - real discriminant));
+//  * for origins within sqrt(far2) of the scene centre the host bounds E once and registers
+//    sphere i in every cell that its bounding square inflated to sqrt(r_i^2 + E) + eps touches;
+//    eps (2^-16 of the largest coordinate in play, >= 25x the rounding of the walk below) lets the
+//    walk be computed in plain fp32 with raw reciprocals: the cells it visits stay within eps of
+//    the true ray, and every point of the true ray inside an inflated ball has that sphere
+//    registered in every cell within eps of it;
+//  * the walk is clipped to the box of the registered (inflated) spheres and to t >= 0 (a sphere
+//    behind the origin has both roots < tmin unless the origin is inside it, and then it is
+//    registered in the origin's cell);
+//  * the walk stops once the next cell boundary lies beyond the nearest accepted root: every
+//    sphere not registered in a visited cell has all its candidate points more than eps beyond
+//    that boundary, so its root is larger;
+//  * rays that start FARTHER away (a bounce off the ground plane hundreds of units out: E grows
+//    with |oc|^2) are clipped against the box of the gridded CENTRES inflated by their own
+//    sqrt(rmax^2 + E(ray)): if the line misses it no gridded sphere can be accepted, otherwise
+//    (a far ray skimming the scene, < 0.01 % of the rays) the whole wave takes the screened
+//    brute-force loop above for this one segment.  NaN / zero / huge rays go the same way.
+// Tested bit for bit against the exact loop on full frames of every scene, both precisions, and
+// on random scenes (tests/test_gpu_parity.py).
+// =====================================================================================
+template <class T>
+__device__ __forceinline__ void direct_trip(const T* g, const int* ids, int s, const LoopRay<T>& r, T& closest, int& hit) {
+    const Trip<T> t = trip_discriminants(g, s, r);
+    const T m = Real<T>::fmax(Real<T>::fmax(t.d0, t.d1), Real<T>::fmax(t.d2, t.d3));
+    if (m >= (T)0) {
+        if (t.d0 >= (T)0) finish_sphere_test<T, true>(ids[s + 0], t.h0, t.d0, r.a, closest, hit);
+        if (t.d1 >= (T)0) finish_sphere_test<T, true>(ids[s + 1], t.h1, t.d1, r.a, closest, hit);
+        if (t.d2 >= (T)0) finish_sphere_test<T, true>(ids[s + 2], t.h2, t.d2, r.a, closest, hit);
+        if (t.d3 >= (T)0) finish_sphere_test<T, true>(ids[s + 3], t.h3, t.d3, r.a, closest, hit);
+    }
+}
+
+// {cx, cy, cz, r*r} of sphere i for the per-lane gathers of the walk: fp32 from the AoS copy in the
+// grid blob (one ds_read_b128), fp64 from geom_a, which is AoS already.
+__device__ __forceinline__ void load_sphere(const float* aos, int i, float& cx, float& cy, float& cz, float& r2) {
+    const v4f c = reinterpret_cast<const v4f*>(aos)[i];
+    cx = c.x; cy = c.y; cz = c.z; r2 = c.w;
+}
+__device__ __forceinline__ void load_sphere(const double* aos, int i, double& cx, double& cy, double& cz, double& r2) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d lo = reinterpret_cast<const v2d*>(aos)[2 * i], hi = reinterpret_cast<const v2d*>(aos)[2 * i + 1];
+    cx = lo.x; cy = lo.y; cz = hi.x; r2 = hi.y;
+}
+
+// The (up to) four spheres of one cell, hittable.h:42-57 each, for this lane's own ray.
+template <class T>
+__device__ __forceinline__ void cell_tests(const T* aos, unsigned rec_lo, unsigned rec_hi, V3<T> O, V3<T> D, T a, T& closest, int& hit) {
+    const int id[4] = {(int)(rec_lo & 0xffffu), (int)(rec_lo >> 16), (int)(rec_hi & 0xffffu), (int)(rec_hi >> 16)};
+    T h[4], disc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        T cx, cy, cz, r2;
+        load_sphere(aos, id[k], cx, cy, cz, r2);
+        const T ocx = cx - O.x, ocy = cy - O.y, ocz = cz - O.z;                         // :42
+        h[k] = RT_FMA(D.z, ocz, RT_FMA(D.y, ocy, D.x * ocx));                            // :44
+        const T c = RT_FMA(ocz, ocz, RT_FMA(ocy, ocy, ocx * ocx)) - r2;                  // :45
+        disc[k] = RT_FMA(h[k], h[k], -(a * c));                                          // :47
+    }
+    const T m = Real<T>::fmax(Real<T>::fmax(disc[0], disc[1]), Real<T>::fmax(disc[2], disc[3]));
+    if (m >= (T)0) {                                                                    // :48 for any of the four
+        PATH_STAT(PS_EXACT_BLOCK);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (disc[k] >= (T)0) finish_sphere_test<T, true>(id[k], h[k], disc[k], a, closest, hit);
+    }
+}
+
+// Clip of o + t d against [lo, hi] on one axis, folded into [t0, t1].  Raw reciprocal: see eps above.
+__device__ __forceinline__ void clip_axis(float o, float d, float lo, float hi, float& t0, float& t1) {
+    if (__builtin_fabsf(d) < 1e-30f) {
+        if (!(o >= lo && o <= hi)) t1 = -__builtin_huge_valf();
+    } else {
+        const float inv = __builtin_amdgcn_rcpf(d);
+        const float ta = (lo - o) * inv, tb = (hi - o) * inv;
+        t0 = __builtin_fmaxf(t0, __builtin_fminf(ta, tb));
+        t1 = __builtin_fminf(t1, __builtin_fmaxf(ta, tb));
+    }
+}
+
+template <class T>
+__device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T* lds_exact, const float* lds_screen,
+                                               V3<T> O, V3<T> D, T a, T& closest, int& hit) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const GridParams& g = p.grid;
+    // ---- which rays the registration margins cover
+    const float fx = (float)(O.x - p.ctr_x), fy = (float)(O.y - p.ctr_y), fz = (float)(O.z - p.ctr_z);
+    const float k2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
+    const float af = (float)a;
+    const bool sane = af > 1e-30f && af < 1e30f && k2 < 1e30f;        // false for NaN as well
+    const bool near = sane && k2 <= g.far2;
+    const float ox = (float)O.x - g.x0, oy = (float)O.y, oz = (float)O.z - g.z0;
+    const float dx = (float)D.x, dy = (float)D.y, dz = (float)D.z;
+    float t0 = 0.0f, t1 = __builtin_huge_valf();
+    float xlo = 0.0f, xhi = (float)g.nx * g.cell, zlo = 0.0f, zhi = (float)g.nz * g.cell, ylo = g.ylo, yhi = g.yhi;
+    if (__builtin_amdgcn_ballot_w64(!near) != 0) {
+        // a far ray: can any gridded sphere pass the reference's discriminant test at all?  Only if the
+        // line comes within rho = sqrt(rmax^2 + E) of a centre, E = 18u((|O'| + Cmax)^2 + rmax^2)
+        // (2^-20 instead of 18 * 2^-24 and the 1.001 cover the raw square roots).
+        const float reach = fast_sqrt(k2) * 1.001f + g.cmax;
+        const float E = 9.5367431640625e-07f * __builtin_fmaf(reach, reach, g.rmax2);
+        const float rho = fast_sqrt(g.rmax2 + E) * 1.001f;
+        if (!near) {
+            xlo = g.core_lo[0] - g.x0 - rho; xhi = g.core_hi[0] - g.x0 + rho;
+            ylo = g.core_lo[1] - rho;        yhi = g.core_hi[1] + rho;
+            zlo = g.core_lo[2] - g.z0 - rho; zhi = g.core_hi[2] - g.z0 + rho;
+        }
+    }
+    clip_axis(oy, dy, ylo, yhi, t0, t1);
+    clip_axis(ox, dx, xlo, xhi, t0, t1);
+    clip_axis(oz, dz, zlo, zhi, t0, t1);
+    const bool crosses = !sane || t0 <= t1;
+    if (__builtin_amdgcn_ballot_w64(!near && crosses) != 0) {
+        hit_world_screened<T>(p, lds_exact, lds_screen, O, D, a, closest, hit);   // exact for every lane of the wave
+        return;
+    }
+    // ---- the direct list: packed trips, every ray
+    {
+        const T* dg = reinterpret_cast<const T*>(smem_raw + g.direct_offset);
+        const int* ids = reinterpret_cast<const int*>(smem_raw + g.direct_ids_offset);
+        const LoopRay<T> r = make_loop_ray(O.x, O.y, O.z, D.x, D.y, D.z, a);
+        for (int s = 0; s < g.n_direct_padded; s += 4) direct_trip<T>(dg, ids, s, r, closest, hit);
+    }
+    // ---- the walk
+    bool walking = near && crosses;
+    if (__builtin_amdgcn_ballot_w64(walking) == 0) return;
+    const T* aos = sizeof(T) == 4 ? reinterpret_cast<const T*>(smem_raw + g.aos_offset) : lds_exact;
+    const uint2* cells = reinterpret_cast<const uint2*>(smem_raw + g.cells_offset);
+    const float px = __builtin_fmaf(t0, dx, ox), pz = __builtin_fmaf(t0, dz, oz);
+    int cx = (int)__builtin_floorf(px * g.inv_cell), cz = (int)__builtin_floorf(pz * g.inv_cell);
+    cx = cx < 0 ? 0 : (cx >= g.nx ? g.nx - 1 : cx);
+    cz = cz < 0 ? 0 : (cz >= g.nz ? g.nz - 1 : cz);
+    const bool step_x = __builtin_fabsf(dx) >= 1e-30f, step_z = __builtin_fabsf(dz) >= 1e-30f;
+    const float inv_dx = step_x ? __builtin_amdgcn_rcpf(dx) : 0.0f, inv_dz = step_z ? __builtin_amdgcn_rcpf(dz) : 0.0f;
+    const int sx = dx > 0.0f ? 1 : -1, sz = dz > 0.0f ? 1 : -1;
+    while (__builtin_amdgcn_ballot_w64(walking) != 0) {
+        if (walking) {
+            PATH_STAT(PS_GRID_STEP);
+            const uint2 rec = cells[cz * g.nx + cx];
+            if (rec.x != 0xffffffffu) cell_tests<T>(aos, rec.x, rec.y, O, D, a, closest, hit);
+            // the parameter at which the ray leaves this cell, per axis
+            const float bx = (float)(cx + (sx > 0 ? 1 : 0)) * g.cell, bz = (float)(cz + (sz > 0 ? 1 : 0)) * g.cell;
+            const float tx = step_x ? (bx - ox) * inv_dx : __builtin_huge_valf();
+            const float tz = step_z ? (bz - oz) * inv_dz : __builtin_huge_valf();
+            const float tnext = __builtin_fminf(tx, tz);
+            const float tend = __builtin_fminf(t1, (float)closest);           // (float) rounds to nearest: covered by eps
+            if (tnext >= tend) walking = false;                               // leaves the slab / the grid, or a nearer hit is known
+            else {
+                if (tx <= tz) cx += sx; else cz += sz;
+                if ((unsigned)cx >= (unsigned)g.nx || (unsigned)cz >= (unsigned)g.nz) walking = false;
+            }
+        }
+    }
+}
+
 template <class T, int SRC>
 __device__ __forceinline__ void hit_world(const RenderParams<T>& p, const T* lds_geom, V3<T> O, V3<T> D, T a, T& closest, int& hit) {
     hit_world_direct<T, SRC>(p, lds_geom, O, D, a, closest, hit);
@@ -501,8 +724,10 @@ __device__ __forceinline__ void hit_world(const RenderParams<T>& p, const T* lds
 template <>
 __device__ __forceinline__ void hit_world<double, RTIOW_SCENE_LDS>(const RenderParams<double>& p, const double* lds_geom, V3<double> O, V3<double> D,
                                                                    double a, double& closest, int& hit) {
-    if (p.use_screen) {
-        extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (p.grid.use_grid) {
+        hit_world_grid<double>(p, lds_geom, reinterpret_cast<const float*>(smem_raw + p.screen_offset), O, D, a, closest, hit);
+    } else if (p.use_screen) {
         hit_world_screened<double>(p, lds_geom, reinterpret_cast<const float*>(smem_raw + p.screen_offset), O, D, a, closest, hit);
     } else {
         hit_world_direct<double, RTIOW_SCENE_LDS>(p, lds_geom, O, D, a, closest, hit);
@@ -511,8 +736,10 @@ __device__ __forceinline__ void hit_world<double, RTIOW_SCENE_LDS>(const RenderP
 template <>
 __device__ __forceinline__ void hit_world<float, RTIOW_SCENE_LDS>(const RenderParams<float>& p, const float* lds_geom, V3<float> O, V3<float> D,
                                                                   float a, float& closest, int& hit) {
-    if (p.use_screen) {
-        extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (p.grid.use_grid) {
+        hit_world_grid<float>(p, lds_geom, reinterpret_cast<const float*>(smem_raw + p.screen_offset), O, D, a, closest, hit);
+    } else if (p.use_screen) {
         hit_world_screened<float>(p, lds_geom, reinterpret_cast<const float*>(smem_raw + p.screen_offset), O, D, a, closest, hit);
     } else {
         hit_world_direct<float, RTIOW_SCENE_LDS>(p, lds_geom, O, D, a, closest, hit);
@@ -724,10 +951,10 @@ __device__ __forceinline__ void hit_world_coop(const RenderParams<T>& p, const T
 }
 
 // camera.h:167-171, color.h:10-13.  The RNG state is deliberately not written back.
-template <class T>
-__device__ __forceinline__ void store_pixel(const RenderParams<T>& p, size_t lp, V3<T> acc) {
-    acc = scale3(p.pixel_samples_scale, acc);
-    T* o = p.fb + lp * 3;
+template <class T, class COLD>
+__device__ __forceinline__ void store_pixel(const COLD& c, size_t lp, V3<T> acc) {
+    acc = scale3((T)c.pixel_samples_scale, acc);
+    T* o = c.fb + lp * 3;
     o[0] = acc.x > (T)0 ? Real<T>::sqrt(acc.x) : (T)0;
     o[1] = acc.y > (T)0 ? Real<T>::sqrt(acc.y) : (T)0;
     o[2] = acc.z > (T)0 ? Real<T>::sqrt(acc.z) : (T)0;
@@ -750,6 +977,11 @@ __device__ __forceinline__ T* stage_scene(const RenderParams<T>& p) {
         if (p.shade_in_lds) {
             T* lds_shade = reinterpret_cast<T*>(smem_raw + p.shade_offset);
             for (int k = threadIdx.x; k < p.n * 12; k += blockDim.x) lds_shade[k] = p.shade_tbl[k];
+        }
+        if (SRC == RTIOW_SCENE_LDS && p.grid.use_grid) {
+            uint32_t* dst = reinterpret_cast<uint32_t*>(smem_raw + p.grid.cells_offset);
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(p.grid.blob);
+            for (int k = threadIdx.x; k < p.grid.blob_bytes / 4; k += blockDim.x) dst[k] = src[k];
         }
         __syncthreads();
     }
@@ -791,14 +1023,13 @@ __device__ __forceinline__ void unpark_state(const unsigned char* base, size_t l
     st.acc = {m.acc[0], m.acc[1], m.acc[2]};
 }
 
-template <class T>
-__device__ __forceinline__ void finish_pixel(const RenderParams<T>& p, size_t lp, size_t npix, const PathState<T>& st, unsigned int cost) {
-    (void)npix;
-    if (p.mid_out) {
-        park_state<T>(p.mid_out, lp, st);
-        p.cost_out[lp] = cost;
+template <class T, class COLD>
+__device__ __forceinline__ void finish_pixel(const COLD& c, size_t lp, const PathState<T>& st, unsigned int cost) {
+    if (c.mid_out) {
+        park_state<T>(c.mid_out, lp, st);
+        c.cost_out[lp] = cost;
     } else {
-        store_pixel(p, lp, st.acc);
+        store_pixel<T>(c, lp, st.acc);
     }
 }
 
@@ -810,29 +1041,30 @@ render_kernel(const RenderParams<T> p) {
     const T* lds_geom = stage_scene<T, SRC>(p);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const T* lds_shade = reinterpret_cast<const T*>(smem_raw + p.shade_offset);
+    const ColdParams<T>& c = p.cold;
     const int tid = threadIdx.x;
     int tx, ty;
-    if (p.wave_tiles) {
+    if (c.wave_tiles) {
         const int wave = tid >> 6, lane = tid & 63;
-        const int tiles_x = p.bx >> 3;
+        const int tiles_x = c.bx >> 3;
         tx = (wave % tiles_x) * 8 + (lane & 7);
         ty = (wave / tiles_x) * 8 + (lane >> 3);
     } else {
-        tx = tid % p.bx;                        // CUDA's threadIdx.x
-        ty = tid / p.bx;                        // CUDA's threadIdx.y
+        tx = tid % c.bx;                        // CUDA's threadIdx.x
+        ty = tid / c.bx;                        // CUDA's threadIdx.y
     }
-    const int i = blockIdx.x * p.bx + tx;
-    const int jl = blockIdx.y * p.by + ty;      // local row
-    if (i >= p.W || jl >= p.local_rows) return; // camera.h:133
-    const int j = global_row(jl, p.strip_rows, p.nranks, p.rank);
-    const size_t lp = (size_t)jl * p.W + i;
+    const int i = blockIdx.x * c.bx + tx;
+    const int jl = blockIdx.y * c.by + ty;      // local row
+    if (i >= c.W || jl >= c.local_rows) return; // camera.h:133
+    const int j = global_row(jl, c.strip_rows, c.nranks, c.rank);
+    const size_t lp = (size_t)jl * c.W + i;
 
-    const size_t npix = (size_t)p.W * p.local_rows;
+    const size_t npix = (size_t)c.W * c.local_rows;
     PathState<T> st;
-    st.rs.v0 = p.rng_in[0 * npix + lp]; st.rs.v1 = p.rng_in[1 * npix + lp]; st.rs.v2 = p.rng_in[2 * npix + lp];   // camera.h:136
-    st.rs.v3 = p.rng_in[3 * npix + lp]; st.rs.v4 = p.rng_in[4 * npix + lp]; st.rs.d = p.rng_in[5 * npix + lp];
+    st.rs.v0 = c.rng_in[0 * npix + lp]; st.rs.v1 = c.rng_in[1 * npix + lp]; st.rs.v2 = c.rng_in[2 * npix + lp];   // camera.h:136
+    st.rs.v3 = c.rng_in[3 * npix + lp]; st.rs.v4 = c.rng_in[4 * npix + lp]; st.rs.d = c.rng_in[5 * npix + lp];
     st.acc = {0, 0, 0};
-    st.sample = p.s_begin; st.depth = 0;          // this launch renders samples [s_begin, s_end)
+    st.sample = c.s_begin; st.depth = 0;          // this launch renders samples [s_begin, s_end)
     unsigned int nseg = 0, cost = 0;
     const int S = p.s_end;
     bool fresh = true;                            // the lane needs a primary ray (camera.h:141-155)
@@ -848,8 +1080,8 @@ render_kernel(const RenderParams<T> p) {
             fresh = true;
         }
     }
-    if (COUNT) { atomicAdd(p.seg_counter, (unsigned long long)nseg); atomicMax(p.seg_counter + 2, (unsigned long long)cost); }
-    finish_pixel(p, lp, npix, st, cost);
+    if (COUNT) { atomicAdd(c.seg_counter, (unsigned long long)nseg); atomicMax(c.seg_counter + 2, (unsigned long long)cost); }
+    finish_pixel<T>(c, lp, st, cost);
 }
 
 // ---- SCHED_PERSISTENT: lanes are not bound to pixels.  Each wave keeps a pool of 64 pixel
@@ -867,10 +1099,7 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const T* lds_shade = reinterpret_cast<const T*>(smem_raw + p.shade_offset);
     CoopSlot<T>* coop_slots = reinterpret_cast<CoopSlot<T>*>(smem_raw + p.coop_offset) + (threadIdx.x >> 6) * 64;
-    const int tiles_x = (p.W + 7) >> 3, tiles_y = (p.local_rows + 7) >> 3;
-    const int total_slots = p.total_slots;
-    const int S = p.s_end;                       // this launch renders samples [p.s_begin, p.s_end)
-    const size_t npix = (size_t)p.W * p.local_rows;
+    const int S = p.s_end;                       // this launch renders samples [cold.s_begin, p.s_end)
 
     PathState<T> st;
     st.acc = {0, 0, 0};
@@ -886,7 +1115,7 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
     // dispatched in blockIdx order and the SIMD arbiter favours older waves, so this puts the
     // heaviest block of the cost-sorted order on the waves that will run fastest.
     const int take = p.lane_cap;                 // slots per refill: 64, fewer in an underfilled launch
-    int first_pool = p.first_pools ? ((int)blockIdx.x * (int)((blockDim.x + 63) >> 6) + (int)(threadIdx.x >> 6)) * take : -1;
+    int first_pool = cold_of(p).first_pools ? ((int)blockIdx.x * (int)((blockDim.x + 63) >> 6) + (int)(threadIdx.x >> 6)) * take : -1;
     unsigned long long t_start = 0, t_exh = 0;
     unsigned int it_normal = 0, it_coop = 0, n_pixels = 0;
     if (COUNT) t_start = __builtin_amdgcn_s_memrealtime();
@@ -898,6 +1127,8 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
         if (!exhausted && __builtin_amdgcn_ballot_w64(!alive && takes_pixels) != 0) {
             bool want = !alive && takes_pixels;
             PATH_STAT(PS_REFILL);
+            const auto& c = cold_of(p);          // image / shard geometry and buffers: scalar loads here, not live in the path loop
+            const int total_slots = c.total_slots;
             for (;;) {
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
                 if (m == 0) break;
@@ -907,7 +1138,7 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
                         base = first_pool;
                         first_pool = -1;
                     } else {
-                        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) base = (int)atomicAdd(p.work_counter, (unsigned)take);
+                        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) base = (int)atomicAdd(c.work_counter, (unsigned)take);
                         base = __builtin_amdgcn_readfirstlane(base);
                     }
                     if (base >= total_slots) { exhausted = true; if (COUNT) t_exh = __builtin_amdgcn_s_memrealtime(); break; }
@@ -922,33 +1153,35 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
                 if (take) {
                     int jl;
                     bool valid;
-                    if (p.order) {                               // cost-sorted hand-out (main launch of the sorted schedule)
-                        const int px = p.order[slot];
+                    if (c.order) {                               // cost-sorted hand-out (main launch of the sorted schedule)
+                        const int px = c.order[slot];
                         valid = px >= 0;
-                        jl = valid ? px / p.W : 0;
-                        i = valid ? px - jl * p.W : 0;
+                        jl = valid ? px / c.W : 0;
+                        i = valid ? px - jl * c.W : 0;
                     } else {                                     // 8x8 tiles, bottom-up
+                        const int tiles_x = (c.W + 7) >> 3, tiles_y = (c.local_rows + 7) >> 3;
                         const int t = slot >> 6, within = slot & 63;
                         const int ty = tiles_y - 1 - t / tiles_x, tx = t % tiles_x;
                         i = tx * 8 + (within & 7);
                         jl = ty * 8 + (within >> 3);
-                        valid = i < p.W && jl < p.local_rows;    // padded slots of ragged tiles are skipped
+                        valid = i < c.W && jl < c.local_rows;    // padded slots of ragged tiles are skipped
                     }
                     if (valid) {
                         want = false;
-                        j = global_row(jl, p.strip_rows, p.nranks, p.rank);
-                        lp = (size_t)jl * p.W + i;
-                        if (p.mid_in) unpark_state<T>(p.mid_in, lp, st);
+                        j = global_row(jl, c.strip_rows, c.nranks, c.rank);
+                        lp = (size_t)jl * c.W + i;
+                        if (c.mid_in) unpark_state<T>(c.mid_in, lp, st);
                         else {
-                            st.rs.v0 = p.rng_in[0 * npix + lp]; st.rs.v1 = p.rng_in[1 * npix + lp]; st.rs.v2 = p.rng_in[2 * npix + lp];
-                            st.rs.v3 = p.rng_in[3 * npix + lp]; st.rs.v4 = p.rng_in[4 * npix + lp]; st.rs.d = p.rng_in[5 * npix + lp];
+                            const size_t npix = (size_t)c.W * c.local_rows;
+                            st.rs.v0 = c.rng_in[0 * npix + lp]; st.rs.v1 = c.rng_in[1 * npix + lp]; st.rs.v2 = c.rng_in[2 * npix + lp];
+                            st.rs.v3 = c.rng_in[3 * npix + lp]; st.rs.v4 = c.rng_in[4 * npix + lp]; st.rs.d = c.rng_in[5 * npix + lp];
                             st.acc = {0, 0, 0};
                         }
-                        st.sample = p.s_begin; st.depth = 0;
+                        st.sample = c.s_begin; st.depth = 0;
                         cost = 0;
                         if (COUNT) ++n_pixels;
-                        if (p.s_begin < S) { alive = true; fresh = true; }
-                        else { finish_pixel(p, lp, npix, st, cost); want = true; }   // nothing to render in this launch
+                        if (c.s_begin < S) { alive = true; fresh = true; }
+                        else { finish_pixel<T>(c, lp, st, cost); want = true; }   // nothing to render in this launch
                     }
                 }
             }
@@ -992,18 +1225,20 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
             if (st.sample < S) fresh = true;
             else {
                 PATH_STAT(PS_FINISH_PIXEL);
-                if (COUNT) atomicMax(p.seg_counter + 2, (unsigned long long)cost);   // a pixel's samples are ONE sequential chain: the frame cannot be shorter than the longest
-                finish_pixel(p, lp, npix, st, cost); alive = false;
+                const auto& c = cold_of(p);
+                if (COUNT) atomicMax(c.seg_counter + 2, (unsigned long long)cost);   // a pixel's samples are ONE sequential chain: the frame cannot be shorter than the longest
+                finish_pixel<T>(c, lp, st, cost); alive = false;
             }
         }
     }
     if (COUNT) {
-        atomicAdd(p.seg_counter, (unsigned long long)nseg);
-        if (p.timeline) {
+        const auto& c = cold_of(p);
+        atomicAdd(c.seg_counter, (unsigned long long)nseg);
+        if (c.timeline) {
             unsigned int px = n_pixels;
             for (int off = 32; off > 0; off >>= 1) px += __shfl_xor(px, off, 64);
             if ((threadIdx.x & 63) == 0) {
-                unsigned long long* o = p.timeline + 8ull * ((unsigned long long)blockIdx.x * ((blockDim.x + 63) >> 6) + (threadIdx.x >> 6));
+                unsigned long long* o = c.timeline + 8ull * ((unsigned long long)blockIdx.x * ((blockDim.x + 63) >> 6) + (threadIdx.x >> 6));
                 o[0] = t_start; o[1] = t_exh; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = it_normal; o[4] = it_coop; o[5] = px; o[6] = 0; o[7] = 0;
             }
         }
@@ -1184,6 +1419,11 @@ struct rtiow_handle_s {
     std::vector<double> host_cr;                  // compact {cx,cy,cz,r} kept for building it
     bool screen_dirty = true;
     double ctr[3] = {0, 0, 0}, omax2 = 0;
+    // uniform grid over the small spheres (RTIOW_SCENE_GRID; built with the screening table)
+    void* grid_blob = nullptr;
+    GridParams grid{};                            // offsets are relative to the blob until launch_render places it in LDS
+    int grid_cells_bytes = 0, grid_aos_bytes = 0, grid_direct_bytes = 0, grid_ids_bytes = 0;
+    int grid_direct = 0, grid_registered = 0;
     // camera
     bool have_camera = false;
     rtiow_camera_f32 cam32{};
@@ -1201,7 +1441,7 @@ struct rtiow_handle_s {
     size_t fb_bytes = 0;
     bool fb_external = false;
     // knobs / stats
-    int scene_source = RTIOW_SCENE_LDS;
+    int scene_source = RTIOW_SCENE_GRID;
     int schedule = RTIOW_SCHED_SORTED;
     unsigned char* mid = nullptr; size_t mid_bytes = 0;          // SCHED_SORTED: MidState records parked between the launches
     uint32_t* cost = nullptr; size_t cost_bytes = 0;
@@ -1271,8 +1511,8 @@ int ensure_framebuffer(rtiow_handle_s* h) {
 template <class T, class CAM>
 RenderParams<T> make_params(const rtiow_handle_s* h, const CAM& c) {
     RenderParams<T> p;
-    p.W = c.img_width; p.H = c.img_height; p.S = c.samples_per_pixel; p.B = c.max_depth;
-    p.pixel_samples_scale = c.pixel_samples_scale;
+    p.cold.W = c.img_width; p.cold.H = c.img_height; p.cold.S = c.samples_per_pixel; p.B = c.max_depth;
+    p.cold.pixel_samples_scale = c.pixel_samples_scale;
     p.center = {c.center[0], c.center[1], c.center[2]};
     p.pixel00 = {c.pixel00_loc[0], c.pixel00_loc[1], c.pixel00_loc[2]};
     p.du = {c.pixel_delta_u[0], c.pixel_delta_u[1], c.pixel_delta_u[2]};
@@ -1282,8 +1522,8 @@ RenderParams<T> make_params(const rtiow_handle_s* h, const CAM& c) {
     p.ddv = {c.defocus_disk_v[0], c.defocus_disk_v[1], c.defocus_disk_v[2]};
     p.n = h->n; p.n_padded = h->n_padded;
     p.geom_a = (const T*)h->geom_a; p.shade_tbl = (const T*)h->shade_tbl;
-    p.rng = h->rng; p.fb = (T*)h->fb;
-    p.local_rows = h->local_rows; p.rank = h->rank; p.nranks = h->nranks; p.strip_rows = h->strip_rows;
+    p.cold.rng = h->rng; p.cold.fb = (T*)h->fb;
+    p.cold.local_rows = h->local_rows; p.cold.rank = h->rank; p.cold.nranks = h->nranks; p.cold.strip_rows = h->strip_rows;
     return p;
 }
 
@@ -1303,7 +1543,7 @@ int upload_scene(rtiow_handle_s* h, int n, const T* cr, const T* af, const T* ri
         ++m;
     }
     if (m == 0) return fail_arg(h, RTIOW_E_BADARG, "scene has no valid spheres");
-    const int mp = (m + 3) / 4 * 4;
+    const int mp = (m + 4) / 4 * 4;                         // >= one padding entry: index m is the never-hit sphere that grid cells pad with
     for (int i = m; i < mp; ++i) ga.insert(ga.end(), {(T)0, (T)0, (T)0, (T)-1e12});   // c = |oc|^2 + 1e12 => disc < 0: never hit
     if (sizeof(T) == 4) {                                    // fp32: pair-interleave for v_pk_*_f32 (trip_discriminants)
         std::vector<T> pi(ga.size());
@@ -1373,10 +1613,181 @@ int build_screen_table(rtiow_handle_s* h) {
     return 0;
 }
 
+// Builds the uniform grid of hit_world_grid for the current scene (after build_screen_table, whose
+// recentring point it shares).  On return h->grid.use_grid says whether the scene has one.
+//
+//  small sphere    : registration half-width w_i = sqrt(r_i^2 + E_i) + eps <= cell / 2, where
+//                    E_i = 18 * 2^-24 ((Rfar + Cmax)^2 + r_i^2) bounds the reference's discriminant
+//                    noise for every origin within Rfar of the recentring point (hit_world_grid);
+//  cell            : about one small sphere per cell, never narrower than the widest small sphere;
+//  registration    : sphere i goes into every cell its square [c - w, c + w]^2 touches (<= 2 x 2),
+//                    in index order; a sphere that meets a full cell (4 entries) joins the direct list;
+//  direct list     : everything else (ground, big spheres, overflow), tested exactly by every ray.
+// The scene keeps the screened loop when the grid would not pay (few small spheres, or a direct
+// list that is no shorter than a fraction of the scene).
+template <class T>
+int build_grid_tables(rtiow_handle_s* h) {
+    GridParams& g = h->grid;
+    g = GridParams{};
+    if (h->grid_blob) { HIP_TRY(h, hipFree(h->grid_blob)); h->grid_blob = nullptr; }
+    const int m = h->n;
+    const std::vector<double>& cr = h->host_cr;
+    if (m < 24 || m > 60000) return 0;
+    std::vector<double> radii(m);
+    for (int i = 0; i < m; ++i) radii[i] = cr[4 * i + 3];
+    // Candidate "small" sets: every finite sphere, then without the largest radii, and so on.  Each
+    // candidate whose cells (one per sphere by area) are at least as wide as its widest member is
+    // registered; the plan with the shortest direct list wins.
+    std::vector<int> small;
+    for (int i = 0; i < m; ++i) {
+        bool ok = radii[i] > 0 && std::isfinite(radii[i]);
+        for (int k = 0; k < 3; ++k) ok = ok && std::isfinite(cr[4 * i + k]);
+        if (ok) small.push_back(i);
+    }
+    std::sort(small.begin(), small.end(), [&](int a, int b) { return radii[a] < radii[b] || (radii[a] == radii[b] && a < b); });
+    const double u18 = 18.0 * std::ldexp(1.0, -24) * 1.01;
+    struct Plan {
+        int nx = 0, nz = 0, registered = 0;
+        float cellf = 0, x0f = 0, z0f = 0;
+        double rfar = 0, ylo = 1e300, yhi = -1e300, core_lo[3] = {1e300, 1e300, 1e300}, core_hi[3] = {-1e300, -1e300, -1e300}, rmax_g = 0, cmax_g = 0;
+        std::vector<uint16_t> cells;
+        std::vector<int> direct;
+    };
+    Plan best;
+    bool have = false;
+    std::vector<double> w(m, 0.0);
+    for (int attempt = 0; attempt < 12 && (int)small.size() >= 16; ++attempt) {
+        double cmax = 0, lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, rmax = 0;
+        for (int i : small) {
+            double d2 = 0;
+            for (int k = 0; k < 3; ++k) { const double d = cr[4 * i + k] - h->ctr[k]; d2 += d * d; lo[k] = std::min(lo[k], cr[4 * i + k]); hi[k] = std::max(hi[k], cr[4 * i + k]); }
+            cmax = std::max(cmax, std::sqrt(d2));
+            rmax = std::max(rmax, radii[i]);
+        }
+        const double cut = 0.9 * rmax;                                  // the next candidate drops the largest radii
+        cmax *= 1.0001;
+        const double rfar = std::max(64.0, 4.0 * cmax);
+        double cabs = 0;
+        for (int k = 0; k < 3; ++k) cabs = std::max(cabs, std::fabs(h->ctr[k]));
+        const double L = 2.0 * (rfar + cmax) + cabs + rmax;            // every coordinate the walk handles is smaller
+        const double eps = std::ldexp(L, -16);
+        double wmax = 0;
+        for (int i : small) {
+            const double E = u18 * ((rfar + cmax) * (rfar + cmax) + radii[i] * radii[i]);
+            w[i] = std::sqrt(radii[i] * radii[i] + E) + eps;
+            wmax = std::max(wmax, w[i]);
+        }
+        const double ext_x = (hi[0] - lo[0]) + 2 * wmax, ext_z = (hi[2] - lo[2]) + 2 * wmax;
+        double cell = std::sqrt(ext_x * ext_z / (double)small.size());
+        const bool usable = L < 1e6 && cell >= 2.0 * (wmax + eps) * 1.02;
+        if (usable) {
+            Plan pl;
+            for (;;) {
+                pl.nx = (int)std::ceil(ext_x / cell) + 1; pl.nz = (int)std::ceil(ext_z / cell) + 1;
+                if ((long long)pl.nx * pl.nz <= 4096) break;
+                cell *= 1.25;
+            }
+            pl.cellf = (float)cell; pl.rfar = rfar;
+            pl.x0f = (float)(lo[0] - wmax - 0.25 * cell); pl.z0f = (float)(lo[2] - wmax - 0.25 * cell);
+            // registration against the cell edges the KERNEL will use (fp32 origin and width), widened by eps again
+            auto cell_of = [&](double v, float origin) { return (int)std::floor((v - (double)origin) / (double)pl.cellf); };
+            const int nx = pl.nx, nz = pl.nz;
+            pl.cells.assign((size_t)nx * nz * 4, 0xffff);
+            std::vector<int> count((size_t)nx * nz, 0);
+            std::vector<char> is_small(m, 0);
+            for (int i : small) is_small[i] = 1;
+            for (int i = 0; i < m; ++i) {
+                if (!is_small[i]) { pl.direct.push_back(i); continue; }
+                const double cx = cr[4 * i], cy = cr[4 * i + 1], cz = cr[4 * i + 2];
+                const int ix0 = cell_of(cx - w[i] - eps, pl.x0f), ix1 = cell_of(cx + w[i] + eps, pl.x0f);
+                const int iz0 = cell_of(cz - w[i] - eps, pl.z0f), iz1 = cell_of(cz + w[i] + eps, pl.z0f);
+                bool fits = ix0 >= 0 && iz0 >= 0 && ix1 < nx && iz1 < nz;
+                for (int iz = iz0; fits && iz <= iz1; ++iz)
+                    for (int ix = ix0; ix <= ix1; ++ix) if (count[(size_t)iz * nx + ix] >= 4) fits = false;
+                if (!fits) { pl.direct.push_back(i); continue; }
+                for (int iz = iz0; iz <= iz1; ++iz)
+                    for (int ix = ix0; ix <= ix1; ++ix) { const size_t c = (size_t)iz * nx + ix; pl.cells[4 * c + count[c]++] = (uint16_t)i; }
+                ++pl.registered;
+                pl.ylo = std::min(pl.ylo, cy - w[i]); pl.yhi = std::max(pl.yhi, cy + w[i]);
+                const double c3[3] = {cx, cy, cz};
+                double d2 = 0;
+                for (int k = 0; k < 3; ++k) { pl.core_lo[k] = std::min(pl.core_lo[k], c3[k]); pl.core_hi[k] = std::max(pl.core_hi[k], c3[k]); const double d = c3[k] - h->ctr[k]; d2 += d * d; }
+                pl.rmax_g = std::max(pl.rmax_g, radii[i]);
+                pl.cmax_g = std::max(pl.cmax_g, std::sqrt(d2));
+            }
+            // a partly filled cell pads with index m, the never-hit entry behind the table (upload_scene)
+            for (size_t c = 0; c < count.size(); ++c)
+                if (count[c] > 0) for (int k = count[c]; k < 4; ++k) pl.cells[4 * c + k] = (uint16_t)m;
+            if (pl.registered >= 16 && (!have || pl.direct.size() < best.direct.size())) { best = std::move(pl); have = true; }
+        }
+        while (!small.empty() && radii[small.back()] >= cut) small.pop_back();
+    }
+    if (!have || (int)best.direct.size() > std::max(8, m / 6)) return 0;
+    const std::vector<uint16_t>& cells = best.cells;
+    const std::vector<int>& direct = best.direct;
+    const int nx = best.nx, nz = best.nz, registered = best.registered;
+    const float cellf = best.cellf, x0f = best.x0f, z0f = best.z0f;
+    const double rfar = best.rfar, ylo = best.ylo, yhi = best.yhi, rmax_g = best.rmax_g, cmax_g = best.cmax_g;
+    const double* core_lo = best.core_lo; const double* core_hi = best.core_hi;
+    // ---- blob: cells | aos (fp32 only) | direct table | direct ids
+    const int nd = (int)direct.size(), ndp = (nd + 3) / 4 * 4;
+    std::vector<T> dtab((size_t)ndp * 4);
+    std::vector<int> ids(ndp, m);
+    for (int k = 0; k < ndp; ++k) {
+        if (k < nd) {
+            const int i = direct[k];
+            const T r = (T)cr[4 * i + 3];
+            dtab[4 * k] = (T)cr[4 * i]; dtab[4 * k + 1] = (T)cr[4 * i + 1]; dtab[4 * k + 2] = (T)cr[4 * i + 2]; dtab[4 * k + 3] = (T)(r * r);   // as upload_scene
+            ids[k] = i;
+        } else { dtab[4 * k] = dtab[4 * k + 1] = dtab[4 * k + 2] = (T)0; dtab[4 * k + 3] = (T)-1e12; }
+    }
+    if (sizeof(T) == 4) {                                    // pair-interleave like geom_a (trip_discriminants)
+        std::vector<T> pi(dtab.size());
+        for (int q = 0; q < ndp / 2; ++q)
+            for (int k = 0; k < 4; ++k) { pi[8 * q + 2 * k] = dtab[8 * q + k]; pi[8 * q + 2 * k + 1] = dtab[8 * q + 4 + k]; }
+        dtab.swap(pi);
+    }
+    std::vector<float> aos;
+    if (sizeof(T) == 4) {
+        aos.resize((size_t)(m + 1) * 4);
+        for (int i = 0; i < m; ++i) {
+            const float r = (float)cr[4 * i + 3];
+            aos[4 * i] = (float)cr[4 * i]; aos[4 * i + 1] = (float)cr[4 * i + 1]; aos[4 * i + 2] = (float)cr[4 * i + 2]; aos[4 * i + 3] = r * r;
+        }
+        aos[4 * m] = aos[4 * m + 1] = aos[4 * m + 2] = 0.0f; aos[4 * m + 3] = -1e12f;
+    }
+    auto align16 = [](size_t v) { return (v + 15) / 16 * 16; };
+    const size_t cells_bytes = align16(cells.size() * sizeof(uint16_t));
+    const size_t aos_bytes = align16(aos.size() * sizeof(float));
+    const size_t dtab_bytes = align16(dtab.size() * sizeof(T));
+    const size_t ids_bytes = align16(ids.size() * sizeof(int));
+    std::vector<unsigned char> blob(cells_bytes + aos_bytes + dtab_bytes + ids_bytes, 0);
+    std::memcpy(blob.data(), cells.data(), cells.size() * sizeof(uint16_t));
+    if (!aos.empty()) std::memcpy(blob.data() + cells_bytes, aos.data(), aos.size() * sizeof(float));
+    std::memcpy(blob.data() + cells_bytes + aos_bytes, dtab.data(), dtab.size() * sizeof(T));
+    std::memcpy(blob.data() + cells_bytes + aos_bytes + dtab_bytes, ids.data(), ids.size() * sizeof(int));
+    HIP_TRY(h, hipMalloc(&h->grid_blob, blob.size()));
+    HIP_TRY(h, hipMemcpy(h->grid_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    h->grid_cells_bytes = (int)cells_bytes; h->grid_aos_bytes = (int)aos_bytes; h->grid_direct_bytes = (int)dtab_bytes; h->grid_ids_bytes = (int)ids_bytes;
+    h->grid_direct = nd; h->grid_registered = registered;
+    g.use_grid = 1;
+    g.nx = nx; g.nz = nz;
+    g.x0 = x0f; g.z0 = z0f; g.cell = cellf; g.inv_cell = (float)(1.0 / (double)cellf);
+    g.ylo = std::nextafter((float)ylo, -INFINITY); g.yhi = std::nextafter((float)yhi, INFINITY);
+    g.far2 = (float)(rfar * rfar * 0.999);
+    for (int k = 0; k < 3; ++k) { g.core_lo[k] = std::nextafter((float)core_lo[k], -INFINITY); g.core_hi[k] = std::nextafter((float)core_hi[k], INFINITY); }
+    g.rmax2 = (float)(rmax_g * rmax_g * 1.0001);
+    g.cmax = (float)(cmax_g * 1.0001);
+    g.n_direct_padded = ndp;
+    g.blob = (const unsigned char*)h->grid_blob;
+    g.blob_bytes = (int)blob.size();
+    return 0;
+}
+
 template <class T>
 void fill_screen_params(RenderParams<T>& p, const rtiow_handle_s* h) {
     p.geom_s = (const float*)h->geom_s;
-    p.use_screen = (h->scene_source == RTIOW_SCENE_LDS && h->geom_s) ? 1 : 0;
+    p.use_screen = ((h->scene_source == RTIOW_SCENE_LDS || h->scene_source == RTIOW_SCENE_GRID) && h->geom_s) ? 1 : 0;
     p.ctr_x = (T)h->ctr[0]; p.ctr_y = (T)h->ctr[1]; p.ctr_z = (T)h->ctr[2]; p.omax2 = (T)h->omax2;
 }
 
@@ -1411,8 +1822,8 @@ template <class T, class CAM>
 int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_tiles, unsigned long long* seg_counter = nullptr,
                   bool prepare_only = false) {
     RenderParams<T> p = make_params<T>(h, cam);
-    p.bx = bx; p.by = by; p.wave_tiles = wave_tiles;
-    p.seg_counter = seg_counter ? seg_counter + 1 : nullptr;     // [0] prepass launch, [1] main (or only) launch
+    p.cold.bx = bx; p.cold.by = by; p.cold.wave_tiles = wave_tiles;
+    p.cold.seg_counter = seg_counter ? seg_counter + 1 : nullptr;     // [0] prepass launch, [1] main (or only) launch
     p.lane_cap = 64;
     const bool persistent = h->schedule != RTIOW_SCHED_STATIC;
     const int threads = bx * by;
@@ -1421,17 +1832,22 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     const size_t coop_scratch = persistent ? (size_t)((threads + 63) / 64) * 64 * sizeof(CoopSlot<T>) : 0;
     bool lds_source = h->scene_source != RTIOW_SCENE_SCALAR;
     int effective_source = h->scene_source;
-    if (lds_source && (sizeof(T) + (h->scene_source == RTIOW_SCENE_LDS ? sizeof(float) : 0)) * 4 * (size_t)h->n_padded + coop_scratch > 160 * 1024) {
+    const bool screened = h->scene_source == RTIOW_SCENE_LDS || h->scene_source == RTIOW_SCENE_GRID;
+    if (lds_source && (sizeof(T) + (screened ? sizeof(float) : 0)) * 4 * (size_t)h->n_padded + coop_scratch > 160 * 1024) {
         lds_source = false;
         effective_source = RTIOW_SCENE_SCALAR;
     }
-    if (lds_source && h->scene_source == RTIOW_SCENE_LDS && h->screen_dirty) { int rc = build_screen_table<T>(h); if (rc) return rc; }
+    if (lds_source && screened && h->screen_dirty) {
+        int rc = build_screen_table<T>(h);
+        if (rc) return rc;
+        if ((rc = build_grid_tables<T>(h))) return rc;
+    }
     fill_screen_params<T>(p, h);
     if (!lds_source) p.use_screen = 0;
     size_t lds = lds_source ? sizeof(T) * 4 * (size_t)h->n_padded : 0;
     p.screen_offset = (int)lds;
     if (p.use_screen) lds += sizeof(float) * 4 * (size_t)h->n_padded;
-    p.timeline = nullptr;                                    // set below, once the grid is known
+    p.cold.timeline = nullptr;                                    // set below, once the grid is known
     // shade records ride along in LDS while a workgroup's share stays within 1/5 of the CU's LDS
     const size_t coop_bytes = persistent ? (size_t)((threads + 63) / 64) * 64 * sizeof(CoopSlot<T>) : 0;
     const size_t shade_bytes = (sizeof(T) * 12 * (size_t)h->n + 15) / 16 * 16;
@@ -1442,6 +1858,16 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     if (p.shade_in_lds) lds += shade_bytes;
     p.coop_offset = (int)lds;                                // a multiple of 16
     lds += coop_bytes;
+    // the grid blob (cells | fp32 AoS table | direct table | direct ids) goes last
+    p.grid = GridParams{};
+    if (lds_source && h->scene_source == RTIOW_SCENE_GRID && p.use_screen && h->grid.use_grid && lds + (size_t)h->grid.blob_bytes <= 160 * 1024) {
+        p.grid = h->grid;
+        p.grid.cells_offset = (int)lds;
+        p.grid.aos_offset = p.grid.cells_offset + h->grid_cells_bytes;
+        p.grid.direct_offset = p.grid.aos_offset + h->grid_aos_bytes;
+        p.grid.direct_ids_offset = p.grid.direct_offset + h->grid_direct_bytes;
+        lds += (size_t)h->grid.blob_bytes;
+    } else if (effective_source == RTIOW_SCENE_GRID) effective_source = RTIOW_SCENE_LDS;   // no grid for this scene: the screened loop
     if (lds > 160 * 1024) return fail_arg(h, RTIOW_E_BADARG, "scene too large for LDS staging; use RTIOW_SCENE_SCALAR");
     RenderFn<T> k = pick_kernel<T>(persistent, lds_source, seg_counter != nullptr);
     if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1460,7 +1886,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             const int cap = (h->waves_per_simd * 4 + waves_per_block - 1) / waves_per_block;
             if (cap < per_cu) per_cu = cap;
         }
-        const long long tile_slots = (long long)((p.W + 7) / 8) * ((h->local_rows + 7) / 8) * POOL;
+        const long long tile_slots = (long long)((p.cold.W + 7) / 8) * ((h->local_rows + 7) / 8) * POOL;
         // Underfilled launch (fewer 64-pixel pools than resident waves: small frames): let only the first
         // `lane_cap` lanes of every wave take pixels.  More waves are busy, each permanently in the
         // cooperative mode, where its idle lanes split the sphere loops of the live ones: a trip gets
@@ -1479,13 +1905,13 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         if (blocks > useful) blocks = useful;               // never more waves than lane_cap-pixel shares of the pools
         grid = dim3((unsigned)blocks);
 
-        const int npix = p.W * h->local_rows;
-        const int S = p.S;
+        const int npix = p.cold.W * h->local_rows;
+        const int S = p.cold.S;
         // prepass length: enough samples to rank the pixels, a small share of the frame
         const int SA = S >= 64 ? 3 : (S >= 24 ? 2 : 0);   // measured on the headline config: 1 -> 25.5 ms, 2 -> 22.5, 3 -> 22.1, 4 -> 22.4, 8 -> 23.1
-        p.work_counter = h->work_counter;
-        p.s_begin = 0; p.s_end = S; p.rng_in = h->rng; p.mid_in = nullptr; p.mid_out = nullptr;
-        p.cost_out = nullptr; p.order = nullptr; p.total_slots = (int)tile_slots; p.first_pools = 0;
+        p.cold.work_counter = h->work_counter;
+        p.cold.s_begin = 0; p.s_end = S; p.cold.rng_in = h->rng; p.cold.mid_in = nullptr; p.cold.mid_out = nullptr;
+        p.cold.cost_out = nullptr; p.cold.order = nullptr; p.cold.total_slots = (int)tile_slots; p.cold.first_pools = 0;
         if (h->schedule == RTIOW_SCHED_SORTED && SA > 0 && npix >= 4096) {
             phases = 2;
             const int total_pools = (npix + POOL - 1) / POOL;
@@ -1499,8 +1925,8 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             // kernel keeps only ~40 % of its lanes busy over a few samples: 2.6 ms vs 1.4 ms measured
             // for 4 samples); RNG state, colour sum and segment count are parked per pixel.
             RenderParams<T> pa = p;
-            pa.s_end = SA; pa.mid_out = h->mid; pa.cost_out = h->cost;
-            pa.seg_counter = seg_counter;
+            pa.s_end = SA; pa.cold.mid_out = h->mid; pa.cold.cost_out = h->cost;
+            pa.cold.seg_counter = seg_counter;
             RenderFn<T> kp = pick_prepass_kernel<T>(lds_source, seg_counter != nullptr);
             if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kp, grid, block, lds, h->stream, pa);
@@ -1528,29 +1954,29 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             // frames are fastest with 1.
             const double pools_per_wave = (double)total_pools / (double)resident_waves;
             const int deal_group = pools_per_wave >= 5.0 ? 16 : (pools_per_wave >= 2.5 ? 8 : 1);
-            const int scatter_blocks = ((p.W + 63) / 64) * ((h->local_rows + 63) / 64);   // one per 64 x 64 super-tile
-            hipLaunchKernelGGL(cost_scatter_kernel, dim3(scatter_blocks), dim3(1024), 0, h->stream, h->cost, p.W, h->local_rows, start, fill, h->order,
+            const int scatter_blocks = ((p.cold.W + 63) / 64) * ((h->local_rows + 63) / 64);   // one per 64 x 64 super-tile
+            hipLaunchKernelGGL(cost_scatter_kernel, dim3(scatter_blocks), dim3(1024), 0, h->stream, h->cost, p.cold.W, h->local_rows, start, fill, h->order,
                                pools_per_block, total_pools, deal_group);
             HIP_TRY(h, hipGetLastError());
             // ---- main launch: samples [SA, S) in that order
-            p.s_begin = SA; p.mid_in = h->mid; p.order = h->order;
-            p.total_slots = total_pools * POOL;
-            p.work_counter = h->work_counter + 1;
-            p.first_pools = 1;
+            p.cold.s_begin = SA; p.cold.mid_in = h->mid; p.cold.order = h->order;
+            p.cold.total_slots = total_pools * POOL;
+            p.cold.work_counter = h->work_counter + 1;
+            p.cold.first_pools = 1;
             const unsigned counter_start = (unsigned)resident_waves * (unsigned)lane_cap;
             HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)(h->work_counter + 1), (int)counter_start, 1, h->stream));
         }
     } else {
-        grid = dim3((p.W + bx - 1) / bx, (h->local_rows + by - 1) / by);
-        p.s_begin = 0; p.s_end = p.S; p.rng_in = h->rng; p.mid_in = nullptr; p.mid_out = nullptr;
-        p.cost_out = nullptr; p.order = nullptr; p.total_slots = 0; p.first_pools = 0; p.work_counter = nullptr;
+        grid = dim3((p.cold.W + bx - 1) / bx, (h->local_rows + by - 1) / by);
+        p.cold.s_begin = 0; p.s_end = p.cold.S; p.cold.rng_in = h->rng; p.cold.mid_in = nullptr; p.cold.mid_out = nullptr;
+        p.cold.cost_out = nullptr; p.cold.order = nullptr; p.cold.total_slots = 0; p.cold.first_pools = 0; p.cold.work_counter = nullptr;
     }
     if (prepare_only) return 0;
     if (seg_counter) {
         h->last_count_blocks = (int)(grid.x * grid.y);
         h->last_count_waves_per_block = (threads + 63) / 64;
         // the kernel writes 8 words per wave: hand the buffer over only if it holds every wave of this launch
-        if (h->timeline && (size_t)h->last_count_blocks * h->last_count_waves_per_block <= h->timeline_cap_waves) p.timeline = h->timeline;
+        if (h->timeline && (size_t)h->last_count_blocks * h->last_count_waves_per_block <= h->timeline_cap_waves) p.cold.timeline = h->timeline;
     }
     if (h->time_phases && phases == 2) HIP_TRY(h, hipEventRecord(h->ev_b, h->stream));
     hipLaunchKernelGGL(k, grid, block, lds, h->stream, p);
@@ -1641,7 +2067,7 @@ int rtiow_destroy(rtiow_handle h) {
     if (!h) return RTIOW_E_BADARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->geom_a, h->shade_tbl, h->geom_s, h->rng, h->jump, h->work_counter, h->mid,
+    void* bufs[] = {h->geom_a, h->shade_tbl, h->geom_s, h->grid_blob, h->rng, h->jump, h->work_counter, h->mid,
                     h->cost, h->order, h->sort_scratch, h->fb_external ? nullptr : h->fb};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1890,7 +2316,8 @@ int rtiow_read_framebuffer(rtiow_handle h, void* host_rgb, size_t bytes) {
 
 int rtiow_set_scene_source(rtiow_handle h, int scene_source) {
     if (!h) return RTIOW_E_BADARG;
-    if (scene_source != RTIOW_SCENE_LDS && scene_source != RTIOW_SCENE_SCALAR && scene_source != RTIOW_SCENE_LDS_EXACT) return fail_arg(h, RTIOW_E_BADARG, "unknown scene source");
+    if (scene_source != RTIOW_SCENE_LDS && scene_source != RTIOW_SCENE_SCALAR && scene_source != RTIOW_SCENE_LDS_EXACT && scene_source != RTIOW_SCENE_GRID)
+        return fail_arg(h, RTIOW_E_BADARG, "unknown scene source");
     h->scene_source = scene_source;
     return 0;
 }

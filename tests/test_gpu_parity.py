@@ -22,7 +22,7 @@ def rt(native):
     return native
 
 
-def _render(rt, prec, scene_id, W, H, S, B, threads=8, source=0, shard=None, seed=1227, sched=2, wps=0):
+def _render(rt, prec, scene_id, W, H, S, B, threads=8, source=3, shard=None, seed=1227, sched=2, wps=0):
     sc = rt.build_scene(scene_id, prec)
     with rt.Renderer(0, prec) as r:
         r.set_camera(rt.camera(prec, W, H, S, B))
@@ -148,7 +148,7 @@ def test_render_bit_exact_vs_oracle(rt, oracle, prec, scene_id, W, H, S, B):
 def test_block_shapes_and_scene_sources_give_the_same_image(rt, oracle):
     want, _ = _oracle(oracle, rt, 32, 3, 100, 60, 3, 12)
     for threads in (0, 1, 4, 8, 16, 32):
-        for source in (rt.SCENE_LDS, rt.SCENE_SCALAR, rt.SCENE_LDS_EXACT):
+        for source in (rt.SCENE_GRID, rt.SCENE_LDS, rt.SCENE_SCALAR, rt.SCENE_LDS_EXACT):
             for sched, wps in ((rt.SCHED_SORTED, 0), (rt.SCHED_PERSISTENT, 0), (rt.SCHED_PERSISTENT, 1), (rt.SCHED_STATIC, 0)):
                 got = _render(rt, 32, 3, 100, 60, 3, 12, threads, source, sched=sched, wps=wps)
                 assert _same_bits(got, want), (threads, source, sched, wps)
@@ -330,9 +330,89 @@ def test_benchmark_harness_csv_round_trip(rt, tmp_path):
     assert len(open(avg).read().splitlines()) == 1 + 4
 
 
+def _custom(rt, prec, scene, W, H, S, B, source, sched=2):
+    with rt.Renderer(0, prec) as r:
+        r.set_camera(rt.camera(prec, W, H, S, B)); r.set_scene(scene); r.set_scene_source(source); r.set_schedule(sched)
+        r.init_rng(1227)
+        r.render(0)
+        return r.read_framebuffer(), r.stats()
+
+
+def test_grid_walk_equals_exact_loop_on_the_reference_scenes(rt):
+    """RTIOW_SCENE_GRID (default: per-lane walk over a uniform grid of the small spheres + direct
+    list) vs the reference's 12-operation test on every sphere, bit for bit, on mid-size frames of
+    all three scenes in both precisions; the stats must say the grid was really used."""
+    for prec, scene_id, W, H, S in ((32, 3, 1280, 720, 20), (32, 1, 1280, 720, 20), (32, 2, 640, 360, 20),
+                                    (64, 3, 640, 360, 20), (64, 1, 640, 360, 10)):
+        sc = rt.build_scene(scene_id, prec)
+        a, st = _custom(rt, prec, sc, W, H, S, 50, rt.SCENE_GRID)
+        assert st["scene_source"] == rt.SCENE_GRID, (prec, scene_id)
+        b, st_b = _custom(rt, prec, sc, W, H, S, 50, rt.SCENE_LDS_EXACT, sched=rt.SCHED_STATIC)
+        assert st_b["scene_source"] == rt.SCENE_LDS_EXACT
+        assert _same_bits(a, b), (prec, scene_id)
+        c, _ = _custom(rt, prec, sc, W, H, S, 50, rt.SCENE_LDS)
+        assert _same_bits(a, c), (prec, scene_id)
+
+
+def _random_field(rng, prec, n, x_range, z_range, radius, y_of, ground=True, big=()):
+    """A scene of n small spheres scattered over a rectangle, optionally with the ground and a few big ones."""
+    dt = np.float32 if prec == 32 else np.float64
+    rows = []
+    if ground:
+        rows.append((0.0, -1000.0, 0.0, 1000.0))
+    rows += list(big)
+    for _ in range(n):
+        r = radius(rng)
+        rows.append((rng.uniform(*x_range), y_of(rng, r), rng.uniform(*z_range), r))
+    cr = np.array(rows, dt)
+    m = len(rows)
+    af = np.zeros((m, 4), dt)
+    af[:, :3] = rng.uniform(0.1, 0.9, (m, 3)); af[:, 3] = rng.uniform(0, 0.5, m)
+    ty = rng.choice([0, 1, 2], m, p=[0.6, 0.2, 0.2]).astype(np.int32)
+    if ground:
+        ty[0] = 0
+    return {"center_radius": cr, "albedo_fuzz": af, "refraction_index": np.full(m, 1.5, dt), "type": ty, "valid": np.ones(m, np.int32)}
+
+
+@pytest.mark.parametrize("case", ["dense_clusters", "mixed_radii_and_heights", "far_from_the_camera", "tiny_spheres", "stacked_no_ground", "touching_pairs"])
+def test_grid_walk_equals_exact_loop_on_random_scenes(rt, oracle, case):
+    """Scenes the grid was not tuned for: full cells that overflow into the direct list, radii near
+    half a cell, spheres at many heights, a field far away from the camera (rays whose origin lies
+    beyond the registration margin's reach: the per-ray clip and the brute-force fallback), tiny
+    spheres (registration margin >> radius), no ground, and touching pairs (equal roots: the
+    lower index must win, hittable.h:54)."""
+    rng = np.random.default_rng({"dense_clusters": 1, "mixed_radii_and_heights": 2, "far_from_the_camera": 3, "tiny_spheres": 4,
+                                 "stacked_no_ground": 5, "touching_pairs": 6}[case])
+    for prec in (32, 64):
+        if case == "dense_clusters":
+            sc = _random_field(rng, prec, 300, (-6, 6), (-6, 6), lambda g: 0.2, lambda g, r: r)
+        elif case == "mixed_radii_and_heights":
+            sc = _random_field(rng, prec, 200, (-10, 8), (-10, 8), lambda g: g.choice([0.1, 0.2, 0.3, 0.45]), lambda g, r: g.uniform(r, 2.0),
+                               big=[(0.0, 1.0, 0.0, 1.0), (4.0, 1.0, 0.0, 1.0)])
+        elif case == "far_from_the_camera":
+            sc = _random_field(rng, prec, 200, (-130, -105), (-32, -18), lambda g: g.uniform(0.1, 0.25), lambda g, r: r)   # 10x its own size away: camera rays are 'far'
+        elif case == "tiny_spheres":
+            sc = _random_field(rng, prec, 250, (-8, 8), (-8, 8), lambda g: g.choice([0.002, 0.01, 0.05]), lambda g, r: g.uniform(0.0, 1.5))
+        elif case == "stacked_no_ground":
+            sc = _random_field(rng, prec, 150, (-4, 6), (-4, 6), lambda g: 0.25, lambda g, r: g.uniform(-3, 4), ground=False)
+        else:
+            sc = _random_field(rng, prec, 240, (-12, 12), (-12, 12), lambda g: 0.2, lambda g, r: r)
+            twin = sc["center_radius"][1:41].copy()
+            sc["center_radius"][201:241] = twin                                    # 40 exact duplicates at higher indices
+            sc["center_radius"][201:221, 0] += np.float32(0.4) if prec == 32 else 0.4   # 20 of them shifted to touch their twin
+        W, H, S, B = 320, 192, 6, 20
+        a, st = _custom(rt, prec, sc, W, H, S, B, rt.SCENE_GRID)
+        assert st["scene_source"] == rt.SCENE_GRID, (case, prec)
+        b, _ = _custom(rt, prec, sc, W, H, S, B, rt.SCENE_LDS_EXACT, sched=rt.SCHED_STATIC)
+        assert _same_bits(a, b), (case, prec)
+        want, _ = oracle.render(prec, sc, rt.camera(prec, 96, 56, 4, 12), 1227)
+        got, _ = _custom(rt, prec, sc, 96, 56, 4, 12, rt.SCENE_GRID)
+        assert _same_bits(got, want), (case, prec)
+
+
 def test_screen_equals_exact_on_the_488_sphere_scene(rt):
     """Scene 1 at 1280x720x20: the screened loop (default) vs the exact loop, bit for bit."""
-    a = _render(rt, 32, 1, 1280, 720, 20, 50, threads=0)
+    a = _render(rt, 32, 1, 1280, 720, 20, 50, threads=0, source=rt.SCENE_LDS)
     b = _render(rt, 32, 1, 1280, 720, 20, 50, threads=0, source=rt.SCENE_LDS_EXACT)
     assert _same_bits(a, b)
 
@@ -340,14 +420,14 @@ def test_screen_equals_exact_on_the_488_sphere_scene(rt):
 def test_screen_equals_exact_fp64(rt, oracle):
     """fp64 screen vs the exact loop on a mid-size frame, and both against oracle rows."""
     W, H, S, B = 640, 360, 20, 50
-    a = _render(rt, 64, 3, W, H, S, B, threads=0)
+    a = _render(rt, 64, 3, W, H, S, B, threads=0, source=rt.SCENE_LDS)
     b = _render(rt, 64, 3, W, H, S, B, threads=0, source=rt.SCENE_LDS_EXACT, sched=rt.SCHED_STATIC)
     assert _same_bits(a, b)
     want, _ = _oracle(oracle, rt, 64, 3, W, H, S, B, rows=(200, 202))
     assert _same_bits(a[200:202], want)
     # the fp64 kernel screens in packed fp32 (rays rounded to fp32 for the screen only): also on
     # the 488-sphere scene, whose centres lie up to 16 units from the recentring point
-    a1 = _render(rt, 64, 1, 320, 192, 10, 25, threads=0)
+    a1 = _render(rt, 64, 1, 320, 192, 10, 25, threads=0, source=rt.SCENE_LDS)
     b1 = _render(rt, 64, 1, 320, 192, 10, 25, threads=0, source=rt.SCENE_LDS_EXACT, sched=rt.SCHED_STATIC)
     assert _same_bits(a1, b1)
 
