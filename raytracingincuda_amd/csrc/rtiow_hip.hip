@@ -208,7 +208,8 @@ template <class T> struct RenderParams {
     int shade_in_lds;                 // 1: the table is staged behind the loop table in LDS (shade_offset bytes)
     int shade_offset;
     int coop_offset;                  // SCHED_PERSISTENT: byte offset of the per-wave coop scratch in LDS
-    GridParams grid;                  // RTIOW_SCENE_GRID: uniform grid over the small spheres (use_grid != 0)
+    int use_grid;                     // RTIOW_SCENE_GRID: hit_world_grid (its description below is read through grid_of)
+    GridParams grid;
     ColdParams<T> cold;
 };
 
@@ -221,6 +222,14 @@ __device__ __forceinline__ const __attribute__((address_space(4))) ColdParams<T>
     kptr k = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(k));
     return *(const __attribute__((address_space(4))) ColdParams<T>*)(k + offsetof(RenderParams<T>, cold));
+}
+// Same for the grid description: ~25 scalars that only hit_world_grid needs, loaded at its entry.
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(4))) GridParams& grid_of(const RenderParams<T>&) {
+    typedef const __attribute__((address_space(4))) char* kptr;
+    kptr k = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return *(const __attribute__((address_space(4))) GridParams*)(k + offsetof(RenderParams<T>, grid));
 }
 
 #define RT_FMA(a, b, c) Real<T>::fma((a), (b), (c))
@@ -646,7 +655,7 @@ template <class T>
 __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T* lds_exact, const float* lds_screen,
                                                V3<T> O, V3<T> D, T a, T& closest, int& hit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const GridParams& g = p.grid;
+    const auto& g = grid_of(p);
     // ---- which rays the registration margins cover
     const float fx = (float)(O.x - p.ctr_x), fy = (float)(O.y - p.ctr_y), fz = (float)(O.z - p.ctr_z);
     const float k2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
@@ -725,7 +734,7 @@ template <>
 __device__ __forceinline__ void hit_world<double, RTIOW_SCENE_LDS>(const RenderParams<double>& p, const double* lds_geom, V3<double> O, V3<double> D,
                                                                    double a, double& closest, int& hit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    if (p.grid.use_grid) {
+    if (p.use_grid) {
         hit_world_grid<double>(p, lds_geom, reinterpret_cast<const float*>(smem_raw + p.screen_offset), O, D, a, closest, hit);
     } else if (p.use_screen) {
         hit_world_screened<double>(p, lds_geom, reinterpret_cast<const float*>(smem_raw + p.screen_offset), O, D, a, closest, hit);
@@ -737,7 +746,7 @@ template <>
 __device__ __forceinline__ void hit_world<float, RTIOW_SCENE_LDS>(const RenderParams<float>& p, const float* lds_geom, V3<float> O, V3<float> D,
                                                                   float a, float& closest, int& hit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    if (p.grid.use_grid) {
+    if (p.use_grid) {
         hit_world_grid<float>(p, lds_geom, reinterpret_cast<const float*>(smem_raw + p.screen_offset), O, D, a, closest, hit);
     } else if (p.use_screen) {
         hit_world_screened<float>(p, lds_geom, reinterpret_cast<const float*>(smem_raw + p.screen_offset), O, D, a, closest, hit);
@@ -978,7 +987,7 @@ __device__ __forceinline__ T* stage_scene(const RenderParams<T>& p) {
             T* lds_shade = reinterpret_cast<T*>(smem_raw + p.shade_offset);
             for (int k = threadIdx.x; k < p.n * 12; k += blockDim.x) lds_shade[k] = p.shade_tbl[k];
         }
-        if (SRC == RTIOW_SCENE_LDS && p.grid.use_grid) {
+        if (SRC == RTIOW_SCENE_LDS && p.use_grid) {
             uint32_t* dst = reinterpret_cast<uint32_t*>(smem_raw + p.grid.cells_offset);
             const uint32_t* src = reinterpret_cast<const uint32_t*>(p.grid.blob);
             for (int k = threadIdx.x; k < p.grid.blob_bytes / 4; k += blockDim.x) dst[k] = src[k];
@@ -1193,13 +1202,14 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
         if (alive && fresh) { gen_primary(p, i, j, st.rs, st.O, st.D, st.sky_uy); st.atten = {1, 1, 1}; fresh = false; }
         bool terminated = false;
         V3<T> col = {0, 0, 0};
+        // hit_world for every lane that still traces (camera.h:84-88), then ONE shade site
+        const bool need_hit = alive && st.depth < p.B;
+        T closest = __builtin_huge_val();
+        int hit = -1;
         if ((exhausted || 2 * p.lane_cap <= wave_lanes) && 2 * __builtin_popcountll(alive_mask) <= wave_lanes) {
             // drain tail: idle lanes share the survivors' sphere loops (hit_world_coop)
             if (COUNT) ++it_coop;
-            const bool need_hit = alive && st.depth < p.B;
             const unsigned long long hit_mask = __builtin_amdgcn_ballot_w64(need_hit);
-            T closest = __builtin_huge_val();
-            int hit = -1;
             if (hit_mask != 0) {
                 const T a = dot3(st.D, st.D);
                 if (sizeof(T) == 4 && wave_lanes == 64 && (hit_mask & (hit_mask - 1)) == 0)
@@ -1207,16 +1217,16 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
                 else
                     hit_world_coop<T, SRC>(p, lds_geom, coop_slots, need_hit, hit_mask, __builtin_popcountll(hit_mask), wave_lanes, st.O, st.D, a, closest, hit);
             }
-            if (alive) {
-                if (need_hit) { ++cost; if (COUNT) ++nseg; }
-                terminated = need_hit ? shade_step<T>(p, lds_shade, st, closest, hit, col) : true;   // camera.h:127 at the depth limit
-            }
         } else {
             if (COUNT) ++it_normal;
-            if (alive) {
-                if (st.depth < p.B) { ++cost; if (COUNT) ++nseg; }
-                terminated = segment_step<T, SRC>(p, lds_geom, lds_shade, st, col);
+            if (need_hit) {
+                const T a = dot3(st.D, st.D);                 // hittable.h:43, ray-invariant
+                hit_world<T, SRC>(p, lds_geom, st.O, st.D, a, closest, hit);
             }
+        }
+        if (alive) {
+            if (need_hit) { ++cost; if (COUNT) ++nseg; }
+            terminated = need_hit ? shade_step<T>(p, lds_shade, st, closest, hit, col) : true;   // camera.h:127 at the depth limit
         }
         if (alive && terminated) {
             st.acc = {st.acc.x + col.x, st.acc.y + col.y, st.acc.z + col.z};       // camera.h:160
@@ -1860,6 +1870,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     lds += coop_bytes;
     // the grid blob (cells | fp32 AoS table | direct table | direct ids) goes last
     p.grid = GridParams{};
+    p.use_grid = 0;
     if (lds_source && h->scene_source == RTIOW_SCENE_GRID && p.use_screen && h->grid.use_grid && lds + (size_t)h->grid.blob_bytes <= 160 * 1024) {
         p.grid = h->grid;
         p.grid.cells_offset = (int)lds;
@@ -1867,6 +1878,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         p.grid.direct_offset = p.grid.aos_offset + h->grid_aos_bytes;
         p.grid.direct_ids_offset = p.grid.direct_offset + h->grid_direct_bytes;
         lds += (size_t)h->grid.blob_bytes;
+        p.use_grid = 1;
     } else if (effective_source == RTIOW_SCENE_GRID) effective_source = RTIOW_SCENE_LDS;   // no grid for this scene: the screened loop
     if (lds > 160 * 1024) return fail_arg(h, RTIOW_E_BADARG, "scene too large for LDS staging; use RTIOW_SCENE_SCALAR");
     RenderFn<T> k = pick_kernel<T>(persistent, lds_source, seg_counter != nullptr);

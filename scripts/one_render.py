@@ -5,7 +5,7 @@ import raytracingincuda_amd as rt
 ap = argparse.ArgumentParser()
 ap.add_argument("--scene", type=int, default=3); ap.add_argument("--w", type=int, default=1920); ap.add_argument("--h", type=int, default=1080)
 ap.add_argument("--s", type=int, default=100); ap.add_argument("--b", type=int, default=50); ap.add_argument("--prec", type=int, default=32)
-ap.add_argument("--sched", type=int, default=1); ap.add_argument("--source", type=int, default=0); ap.add_argument("--threads", type=int, default=0)
+ap.add_argument("--sched", type=int, default=1); ap.add_argument("--source", type=int, default=3); ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--reps", type=int, default=3); ap.add_argument("--wps", type=int, default=0)
 a = ap.parse_args()
 r = rt.Renderer(0, a.prec); r.set_camera(rt.camera(a.prec, a.w, a.h, a.s, a.b)); r.set_scene(rt.build_scene(a.scene, a.prec))
