@@ -4,6 +4,7 @@
 // host code is compiled by g++ for x86-64 without FMA.
 #include "rtiow_host.h"
 
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -152,6 +153,9 @@ void camera_t(int width, int height, int samples, int bounces, CAM* cam) {
 
 template <class T> inline int to_level(T c) {                   // main.cu:367,374-376; interval.h:25-29
     const T lo = (T)0.000, hi = (T)0.999;
+    // clamp() passes a NaN through and int(NaN) is undefined in the reference; its x86 build yields
+    // INT_MIN ("-2147483648" in the file).  Same text here, without the undefined conversion.
+    if (!(c == c)) return INT_MIN;
     const T cl = c < lo ? lo : (c > hi ? hi : c);
     return (int)(256 * cl);
 }
@@ -166,9 +170,10 @@ void format_ppm_t(int width, int height, const T* rgb, std::string& out) {
     const size_t npix = (size_t)width * height;
     for (size_t p = 0; p < npix; ++p) {
         for (int k = 0; k < 3; ++k) {
-            int v = to_level<T>(rgb[3 * p + k]);
+            const int level = to_level<T>(rgb[3 * p + k]);
+            unsigned v = (unsigned)level;
             int n = 0;
-            if (v < 0) { out.push_back('-'); v = -v; }         // int(NaN) is UB in the reference; keep the text well-formed
+            if (level < 0) { out.push_back('-'); v = 0u - v; } // only the NaN level is negative; unsigned negation is defined for INT_MIN
             do { digits[n++] = (char)('0' + v % 10); v /= 10; } while (v);
             while (n) out.push_back(digits[--n]);
             out.push_back(k == 2 ? '\n' : ' ');

@@ -284,6 +284,9 @@ template <class T> __device__ __forceinline__ V3<T> random_unit_vector(Rng& s) {
         z = RT_FMA(Real<T>::uniform(s), (T)2, (T)-1);
         lensq = RT_FMA(z, z, RT_FMA(y, y, x * x));
         if (Real<T>::ruv_eps < lensq && lensq <= (T)1) break;
+#ifdef RTIOW_ABLATE_RUV_ROUNDS
+        lensq = (T)0.5; break;
+#endif
     }
     const T inv = (T)1 / Real<T>::sqrt(lensq);
     return {inv * x, inv * y, inv * z};
@@ -307,6 +310,9 @@ __device__ __forceinline__ void gen_primary(const RenderParams<T>& p, int i, int
             px = RT_FMA((T)2, Real<T>::uniform(s), (T)-1);
             py = RT_FMA((T)2, Real<T>::uniform(s), (T)-1);
             if (RT_FMA(py, py, px * px) < (T)1) break;
+#ifdef RTIOW_ABLATE_DISK_ROUNDS
+            break;
+#endif
         }
         org = madd3(py, p.ddv, madd3(px, p.ddu, p.center));
     }
@@ -692,10 +698,15 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
         const T* dg = reinterpret_cast<const T*>(smem_raw + g.direct_offset);
         const int* ids = reinterpret_cast<const int*>(smem_raw + g.direct_ids_offset);
         const LoopRay<T> r = make_loop_ray(O.x, O.y, O.z, D.x, D.y, D.z, a);
+#ifndef RTIOW_ABLATE_DIRECT
         for (int s = 0; s < g.n_direct_padded; s += 4) direct_trip<T>(dg, ids, s, r, closest, hit);
+#endif
     }
     // ---- the walk
     bool walking = near && crosses;
+#ifdef RTIOW_ABLATE_WALK
+    walking = false;
+#endif
     if (__builtin_amdgcn_ballot_w64(walking) == 0) return;
     const T* aos = sizeof(T) == 4 ? reinterpret_cast<const T*>(smem_raw + g.aos_offset) : lds_exact;
     const uint2* cells = reinterpret_cast<const uint2*>(smem_raw + g.cells_offset);
@@ -1920,7 +1931,10 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         const int npix = p.cold.W * h->local_rows;
         const int S = p.cold.S;
         // prepass length: enough samples to rank the pixels, a small share of the frame
-        const int SA = S >= 64 ? 3 : (S >= 24 ? 2 : 0);   // measured on the headline config: 1 -> 25.5 ms, 2 -> 22.5, 3 -> 22.1, 4 -> 22.4, 8 -> 23.1
+        int SA = S >= 64 ? 3 : (S >= 24 ? 2 : 0);
+#ifdef RTIOW_TUNING
+        if (const char* e = std::getenv("RTIOW_TUNE_SA")) SA = std::atoi(e);          // tuning build only (scripts/tune_sweep.py)
+#endif   // measured on the headline config: 1 -> 25.5 ms, 2 -> 22.5, 3 -> 22.1, 4 -> 22.4, 8 -> 23.1
         p.cold.work_counter = h->work_counter;
         p.cold.s_begin = 0; p.s_end = S; p.cold.rng_in = h->rng; p.cold.mid_in = nullptr; p.cold.mid_out = nullptr;
         p.cold.cost_out = nullptr; p.cold.order = nullptr; p.cold.total_slots = (int)tile_slots; p.cold.first_pools = 0;
@@ -1965,7 +1979,10 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             // full frame 24.1 -> 22.5 ms with 16-32, half frame 14.7 -> 14.0 with 8, quarter and eighth
             // frames are fastest with 1.
             const double pools_per_wave = (double)total_pools / (double)resident_waves;
-            const int deal_group = pools_per_wave >= 5.0 ? 16 : (pools_per_wave >= 2.5 ? 8 : 1);
+            int deal_group = pools_per_wave >= 5.0 ? 16 : (pools_per_wave >= 2.5 ? 8 : 1);
+#ifdef RTIOW_TUNING
+            if (const char* e = std::getenv("RTIOW_TUNE_DEAL")) deal_group = std::atoi(e);
+#endif
             const int scatter_blocks = ((p.cold.W + 63) / 64) * ((h->local_rows + 63) / 64);   // one per 64 x 64 super-tile
             hipLaunchKernelGGL(cost_scatter_kernel, dim3(scatter_blocks), dim3(1024), 0, h->stream, h->cost, p.cold.W, h->local_rows, start, fill, h->order,
                                pools_per_block, total_pools, deal_group);
