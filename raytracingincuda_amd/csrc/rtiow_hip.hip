@@ -267,8 +267,22 @@ __device__ __forceinline__ void path_stat(int region) {
     }
 }
 #define PATH_STAT(r) path_stat(r)
+// Region clocks of the same build: shader cycles a WAVE spends between two points, summed over all
+// waves (s_memtime; the reads themselves cost ~10 % and other waves' issue slots are included, so
+// only the proportions mean something).  scripts/path_stats_probe.py prints them.
+enum { RG_REFILL = 0, RG_GEN_PRIMARY, RG_HIT_WORLD, RG_HIT_COOP, RG_SHADE, RG_ACCUMULATE, RG_GRID_SETUP, RG_GRID_DIRECT, RG_GRID_WALK, RG_GRID_FALLBACK,
+       RG_RUV_ROUNDS, RG_LOOP_TOTAL, RG_COUNT };
+__device__ unsigned long long g_region_cycles[RG_COUNT];
+__device__ __forceinline__ void region_add(int region, unsigned long long t0) {
+    const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd(&g_region_cycles[region], dt);
+}
+#define REGION_BEGIN(name) const unsigned long long rg_##name = __builtin_amdgcn_s_memtime()
+#define REGION_END(name, region) region_add(region, rg_##name)
 #else
 #define PATH_STAT(r) ((void)0)
+#define REGION_BEGIN(name) ((void)0)
+#define REGION_END(name, region) ((void)0)
 #endif
 
 template <class T> __device__ __forceinline__ V3<T> random_unit_vector(Rng& s) {   // vec3.h:117-127
@@ -277,6 +291,7 @@ template <class T> __device__ __forceinline__ V3<T> random_unit_vector(Rng& s) {
     // executes for its slowest lane.  Same draws, same arithmetic on the accepted candidate.
     T x, y, z, lensq;
     PATH_STAT(PS_RUV_CALL);
+    REGION_BEGIN(ruv);
     for (;;) {
         PATH_STAT(PS_RUV_ROUND);
         x = RT_FMA(Real<T>::uniform(s), (T)2, (T)-1);
@@ -288,6 +303,7 @@ template <class T> __device__ __forceinline__ V3<T> random_unit_vector(Rng& s) {
         lensq = (T)0.5; break;
 #endif
     }
+    REGION_END(ruv, RG_RUV_ROUNDS);
     const T inv = (T)1 / Real<T>::sqrt(lensq);
     return {inv * x, inv * y, inv * z};
 }
@@ -347,19 +363,31 @@ __device__ __forceinline__ double fast_sqrt(double x) { return __builtin_amdgcn_
 // loop keeps the FIRST sphere among equal roots (`root < closest_so_far` is strict, hittable.h:54-56),
 // i.e. its result is the lexicographic minimum of (t, index); out of order that is `root < closest,
 // or root == closest and a lower index`.  Testing a sphere twice changes nothing.
+template <class T>
+__device__ __forceinline__ bool root_pretest_rejects(T h, T disc, T a, T closest) {
+    const T tmin = (T)0.001;
+    const T kappa = (T)2.384185791015625e-07;                      // 2^-22
+    const T sq_approx = fast_sqrt(disc);
+    const T e = RT_FMA(kappa, Real<T>::fabs(h) + sq_approx, (T)8.673617379884035e-19);   // + 2^-60
+    const T behind_bound = (tmin * a) * (T)0.99999904632568359375;  // tmin*a*(1-2^-20)
+    const T far_bound = (closest * a) * (T)1.00000095367431640625; // closest*a*(1+2^-20); inf while nothing is hit
+    return ((h + sq_approx) + e < behind_bound) || ((h - sq_approx) - e > far_bound);
+}
+
+template <class T, bool ANYORDER = false>
+__device__ __forceinline__ void ieee_roots(int s, T h, T disc, T a, T& closest, int& hit);
+
 template <class T, bool ANYORDER = false>
 __device__ __forceinline__ void finish_sphere_test(int s, T h, T disc, T a, T& closest, int& hit) {
-    const T tmin = (T)0.001;
     PATH_STAT(PS_FINISH_CALL);
-    {
-        const T kappa = (T)2.384185791015625e-07;                      // 2^-22
-        const T sq_approx = fast_sqrt(disc);
-        const T e = RT_FMA(kappa, Real<T>::fabs(h) + sq_approx, (T)8.673617379884035e-19);   // + 2^-60
-        const T behind_bound = (tmin * a) * (T)0.99999904632568359375;  // tmin*a*(1-2^-20)
-        const T far_bound = (closest * a) * (T)1.00000095367431640625; // closest*a*(1+2^-20); inf while nothing is hit
-        if ((h + sq_approx) + e < behind_bound) return;
-        if ((h - sq_approx) - e > far_bound) return;
-    }
+    if (root_pretest_rejects<T>(h, disc, a, closest)) return;
+    ieee_roots<T, ANYORDER>(s, h, disc, a, closest, hit);
+}
+
+// hittable.h:50-57 proper.
+template <class T, bool ANYORDER>
+__device__ __forceinline__ void ieee_roots(int s, T h, T disc, T a, T& closest, int& hit) {
+    const T tmin = (T)0.001;
     PATH_STAT(PS_IEEE_BLOCK);
     const T sq = Real<T>::sqrt(disc);                               // :50
     T root = (h - sq) / a;                                          // :53
@@ -662,6 +690,7 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
                                                V3<T> O, V3<T> D, T a, T& closest, int& hit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const auto& g = grid_of(p);
+    REGION_BEGIN(setup);
     // ---- which rays the registration margins cover
     const float fx = (float)(O.x - p.ctr_x), fy = (float)(O.y - p.ctr_y), fz = (float)(O.z - p.ctr_z);
     const float k2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
@@ -689,10 +718,14 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
     clip_axis(ox, dx, xlo, xhi, t0, t1);
     clip_axis(oz, dz, zlo, zhi, t0, t1);
     const bool crosses = !sane || t0 <= t1;
+    REGION_END(setup, RG_GRID_SETUP);
     if (__builtin_amdgcn_ballot_w64(!near && crosses) != 0) {
+        REGION_BEGIN(fallback);
         hit_world_screened<T>(p, lds_exact, lds_screen, O, D, a, closest, hit);   // exact for every lane of the wave
+        REGION_END(fallback, RG_GRID_FALLBACK);
         return;
     }
+    REGION_BEGIN(direct);
     // ---- the direct list: packed trips, every ray
     {
         const T* dg = reinterpret_cast<const T*>(smem_raw + g.direct_offset);
@@ -702,12 +735,14 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
         for (int s = 0; s < g.n_direct_padded; s += 4) direct_trip<T>(dg, ids, s, r, closest, hit);
 #endif
     }
+    REGION_END(direct, RG_GRID_DIRECT);
     // ---- the walk
+    REGION_BEGIN(walk);
     bool walking = near && crosses;
 #ifdef RTIOW_ABLATE_WALK
     walking = false;
 #endif
-    if (__builtin_amdgcn_ballot_w64(walking) == 0) return;
+    if (__builtin_amdgcn_ballot_w64(walking) == 0) { REGION_END(walk, RG_GRID_WALK); return; }
     const T* aos = sizeof(T) == 4 ? reinterpret_cast<const T*>(smem_raw + g.aos_offset) : lds_exact;
     const uint2* cells = reinterpret_cast<const uint2*>(smem_raw + g.cells_offset);
     const float px = __builtin_fmaf(t0, dx, ox), pz = __builtin_fmaf(t0, dz, oz);
@@ -735,6 +770,7 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
             }
         }
     }
+    REGION_END(walk, RG_GRID_WALK);
 }
 
 template <class T, int SRC>
@@ -1144,6 +1180,8 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
     const int wave_lanes = lanes_left < 64 ? lanes_left : 64;   // partial last wave of a T x T block
 
     for (;;) {
+        REGION_BEGIN(total);
+        REGION_BEGIN(refill);
         if (!exhausted && __builtin_amdgcn_ballot_w64(!alive && takes_pixels) != 0) {
             bool want = !alive && takes_pixels;
             PATH_STAT(PS_REFILL);
@@ -1206,11 +1244,14 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
                 }
             }
         }
+        REGION_END(refill, RG_REFILL);
         const unsigned long long alive_mask = __builtin_amdgcn_ballot_w64(alive);
         if (alive_mask == 0) break;
         if (alive) PATH_STAT(PS_ITERATION);
         // one site generates every primary ray: first sample of a new pixel or the next sample
+        REGION_BEGIN(gen);
         if (alive && fresh) { gen_primary(p, i, j, st.rs, st.O, st.D, st.sky_uy); st.atten = {1, 1, 1}; fresh = false; }
+        REGION_END(gen, RG_GEN_PRIMARY);
         bool terminated = false;
         V3<T> col = {0, 0, 0};
         // hit_world for every lane that still traces (camera.h:84-88), then ONE shade site
@@ -1220,6 +1261,7 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
         if ((exhausted || 2 * p.lane_cap <= wave_lanes) && 2 * __builtin_popcountll(alive_mask) <= wave_lanes) {
             // drain tail: idle lanes share the survivors' sphere loops (hit_world_coop)
             if (COUNT) ++it_coop;
+            REGION_BEGIN(coop);
             const unsigned long long hit_mask = __builtin_amdgcn_ballot_w64(need_hit);
             if (hit_mask != 0) {
                 const T a = dot3(st.D, st.D);
@@ -1228,17 +1270,23 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
                 else
                     hit_world_coop<T, SRC>(p, lds_geom, coop_slots, need_hit, hit_mask, __builtin_popcountll(hit_mask), wave_lanes, st.O, st.D, a, closest, hit);
             }
+            REGION_END(coop, RG_HIT_COOP);
         } else {
             if (COUNT) ++it_normal;
+            REGION_BEGIN(hw);
             if (need_hit) {
                 const T a = dot3(st.D, st.D);                 // hittable.h:43, ray-invariant
                 hit_world<T, SRC>(p, lds_geom, st.O, st.D, a, closest, hit);
             }
+            REGION_END(hw, RG_HIT_WORLD);
         }
+        REGION_BEGIN(shade);
         if (alive) {
             if (need_hit) { ++cost; if (COUNT) ++nseg; }
             terminated = need_hit ? shade_step<T>(p, lds_shade, st, closest, hit, col) : true;   // camera.h:127 at the depth limit
         }
+        REGION_END(shade, RG_SHADE);
+        REGION_BEGIN(acc);
         if (alive && terminated) {
             st.acc = {st.acc.x + col.x, st.acc.y + col.y, st.acc.z + col.z};       // camera.h:160
             ++st.sample;
@@ -1251,6 +1299,8 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
                 finish_pixel<T>(c, lp, st, cost); alive = false;
             }
         }
+        REGION_END(acc, RG_ACCUMULATE);
+        REGION_END(total, RG_LOOP_TOTAL);
     }
     if (COUNT) {
         const auto& c = cold_of(p);
@@ -1979,7 +2029,9 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             // full frame 24.1 -> 22.5 ms with 16-32, half frame 14.7 -> 14.0 with 8, quarter and eighth
             // frames are fastest with 1.
             const double pools_per_wave = (double)total_pools / (double)resident_waves;
-            int deal_group = pools_per_wave >= 5.0 ? 16 : (pools_per_wave >= 2.5 ? 8 : 1);
+            // With the grid walk (a lane's cost follows ITS ray) coherence pays more: whole pools of 64 neighbouring
+            // ranks on the full frame, 15.3 -> 14.7 ms; the smaller frames keep their mix (profiles/r02_tune_sweep.jsonl).
+            int deal_group = pools_per_wave >= 5.0 ? 64 : (pools_per_wave >= 2.5 ? 8 : 1);
 #ifdef RTIOW_TUNING
             if (const char* e = std::getenv("RTIOW_TUNE_DEAL")) deal_group = std::atoi(e);
 #endif
@@ -2043,6 +2095,11 @@ int rtiow_abi_version(void) { return RTIOW_ABI_VERSION; }
 
 #ifdef RTIOW_PATH_STATS
 // stats build only: read (reset != 0: clear) the execution profile, 2 words per region
+int rtiow_debug_region_cycles(unsigned long long* out, int cap_words, int reset) {
+    if (reset) { unsigned long long z[RG_COUNT] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_region_cycles), z, sizeof z); }
+    if (!out || cap_words < RG_COUNT) return RTIOW_E_BADARG;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_region_cycles), RG_COUNT * sizeof(unsigned long long));
+}
 int rtiow_debug_path_stats(unsigned long long* out, int cap_words, int reset) {
     if (reset) { unsigned long long z[2 * PS_COUNT] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_path_stats), z, sizeof z); }
     if (!out || cap_words < 2 * PS_COUNT) return RTIOW_E_BADARG;

@@ -18,7 +18,11 @@ r.init_rng(1227); r.set_schedule(rt.SCHED_SORTED, 0)
 lib = api.load_hip_library()
 buf = (ctypes.c_ulonglong * (2 * len(names)))()
 assert lib.rtiow_debug_path_stats(buf, len(buf), 1) == 0
+regions = ["refill", "gen_primary", "hit_world", "hit_coop", "shade", "accumulate", "grid_setup", "grid_direct", "grid_walk", "grid_fallback", "ruv_rounds", "loop_total"]
+rbuf = (ctypes.c_ulonglong * len(regions))()
+assert lib.rtiow_debug_region_cycles(rbuf, len(rbuf), 1) == 0
 r.render(0)
+assert lib.rtiow_debug_region_cycles(rbuf, len(rbuf), 0) == 0
 assert lib.rtiow_debug_path_stats(buf, len(buf), 0) == 0
 v = list(buf)
 it = float(v[0])
@@ -26,5 +30,8 @@ out = {"config": "scene %d %dx%d %d spp %d bounces fp32, sorted schedule (prepas
        "lanes_per_iteration": round(v[1] / it, 2), "per_wave_iteration": {}}
 for k, n in enumerate(names[1:], 1):
     out["per_wave_iteration"][n] = {"wave_executions": round(v[2 * k] / it, 3), "active_lanes_each": round(v[2 * k + 1] / max(v[2 * k], 1), 1)}
+tot = float(rbuf[len(regions) - 1]) or 1.0
+out["region_share_of_loop_cycles"] = {n: round(rbuf[k] / tot, 4) for k, n in enumerate(regions)}
+out["region_note"] = "grid_* lie inside hit_world, ruv_rounds inside shade; s_memtime reads cost ~10 %, shares only"
 print(json.dumps(out, indent=1))
 r.close()
