@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--schedule", default="sorted", choices=("sorted", "persistent", "static"))
     ap.add_argument("--strip_rows", type=int, default=0, help="rows per interleaved strip; 0 = 8 for N <= 2, 2 for N >= 4 (profiles/r01_strip_rows_sweep.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scaling-probe", action="store_true",
+                    help="skip the 1-pixel lone-ray probe (it launches the main kernel by the same name: keeps rocprofv3 --stats averages clean)")
     return ap.parse_args()
 
 
@@ -135,6 +137,24 @@ def pmc_traffic(args):
     e = json.load(open(path)).get(key, {})
     f, w = e.get("main_launch_FETCH_SIZE_KB"), e.get("main_launch_WRITE_SIZE_KB")
     return (e.get("hbm_bytes_main_launch", e.get("hbm_bytes_per_launch")), f * 1024.0 if f is not None else None, w * 1024.0 if w is not None else None)
+
+
+def pmc_issue(args):
+    """Vector-instruction issue of the main launch from the committed rocprofv3 --pmc passes (the newest
+    profiles/r*_pmc_sq_final.json; headline configuration only): wave-instructions per launch and SIMD cycles per
+    instruction.  A wave64 VALU instruction occupies a SIMD-32 for at least 2 cycles, so 2 / cycles-per-
+    instruction is the fraction of the vector issue peak the launch reaches."""
+    import glob
+    if (args.scene_id, args.width, args.height, args.samples, args.bounces, args.precision, args.schedule, args.scene_source) != (3, 1920, 1080, 100, 50, 32, "sorted", "grid"):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_final.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1])).get("counters", {}).get("derived_main")
+    if not d:
+        return None
+    return {"valu_wave_insts_per_launch": d["valu_insts_per_launch"], "simd_cycles_per_valu_inst": round(d["simd_cycles_per_valu_inst"], 3),
+            "valu_issue_frac": round(2.0 / d["simd_cycles_per_valu_inst"], 4), "source": os.path.relpath(files[-1], ROOT)}
 
 
 def lone_ray_trip_us(rt, device_index, prec, scene, args):
@@ -209,7 +229,7 @@ def main():
     nspheres = r.stats()["num_spheres"]
 
     chain_main = int(r.stats()["max_chain_main"])      # this rank's longest per-pixel chain in the main launch
-    trip_us, trip_segments = lone_ray_trip_us(rt, device_index, prec, scene, args)
+    trip_us, trip_segments = (None, 0) if args.no_scaling_probe else lone_ray_trip_us(rt, device_index, prec, scene, args)
 
     main_ms = []
     gather_events = []
@@ -304,7 +324,11 @@ def main():
                          "algorithmic_flops_per_launch": flops, "segments_in_launch": int(st["segments_main"]),
                          "samples_in_launch": int(S - st["prepass_samples"]),
                          "algorithmic_hbm_bytes_per_launch": fb_bytes,
-                         "hbm_achieved_GBps": round(fb_bytes / (mms * 1e-3) / 1e9, 3), "hbm_peak_GBps": HBM_PEAK_GBS},
+                         "hbm_achieved_GBps": round(fb_bytes / (mms * 1e-3) / 1e9, 3), "hbm_peak_GBps": HBM_PEAK_GBS,
+                         "achieved_is": "ALGORITHMIC flops per second: the reference's own sphere loop, 23 flop x every sphere x every segment (SURVEY.md 8d). "
+                                        "The grid walk finds the same hits testing a few spheres per segment, so this figure measures useful work against the "
+                                        "reference's algorithm, not executed arithmetic, and can exceed the peak; 'issued' is what the hardware executed",
+                         "issued": pmc_issue(args) if world == 1 else None},
             "step": {"launches": "prepass (%d spp) + cost sort + main" % st["prepass_samples"] if st["phases"] == 2 else "main",
                      "kernel_ms_mean": round(kms, 4), "prepass_ms": round(float(st["prepass_ms"]), 4),
                      "algorithmic_flops": flops_step, "achieved_TFLOPs": round(flops_step / (kms * 1e-3) / 1e12, 3),

@@ -12,6 +12,7 @@ def last_json(path):
 
 for name, out in (("bench_n1.json", "bench_n1"), ("bench_n1_f64.json", "bench_n1_f64"), ("bench_n1_scene1.json", "bench_n1_scene1"),
                   ("bench_n1_static_t8.json", "bench_n1_static_t8"), ("bench_under_rocprof.json", "bench_under_rocprof"),
+                  ("bench_n1_screen_only.json", "bench_n1_screen_only"), ("bench_n1_scene1_screen_only.json", "bench_n1_scene1_screen_only"),
                   ("bench_config2_scene1_320x192.json", "bench_config2_scene1_320x192"), ("bench_config3_1280x720.json", "bench_config3_1280x720"),
                   ("bench_config5_f64_500spp.json", "bench_config5_f64_500spp")):
     if not os.path.exists(os.path.join(src, name)):
@@ -23,7 +24,7 @@ b = last_json(os.path.join(src, "bench_under_rocprof.json"))
 rows = list(csv.DictReader(open(stats)))
 main = [r for r in rows if "render_persistent_kernel<float, 0, false>" in r["Name"]][0]
 pre = [r for r in rows if "render_prepass_kernel<float, 0, false>" in r["Name"]]
-agree = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline",
+agree = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-scaling-probe",
          "rocprof_main_launch_avg_ms": float(main["AverageNs"]) / 1e6, "rocprof_main_launch_calls": int(main["Calls"]),
          "bench_roofline_launch_ms_mean": b["roofline"]["launch_ms_mean"],
          "rocprof_prepass_avg_ms": float(pre[0]["AverageNs"]) / 1e6 if pre else None, "bench_prepass_ms": b["step"]["prepass_ms"],
@@ -44,10 +45,17 @@ for d in ("pmc_sq", "pmc_sq2"):
             if k: per.setdefault((k, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
         for (k, c), v in per.items():
             sq.setdefault(k, {})[c] = sum(v) / len(v)
+# what the counters say about issue: vector instructions per launch and SIMD cycles per instruction
+m = sq.get("main", {})
+if m.get("SQ_INSTS_VALU") and m.get("GRBM_GUI_ACTIVE"):
+    simd_cycles = m["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0             # GRBM_GUI_ACTIVE sums the 8 XCDs; 256 CUs x 4 SIMDs
+    sq["derived_main"] = {"valu_insts_per_launch": m["SQ_INSTS_VALU"], "simd_cycles_per_valu_inst": simd_cycles / m["SQ_INSTS_VALU"],
+                          "lane_insts_per_launch": m["SQ_INSTS_VALU"] * 64.0,
+                          "note": "SQ_INSTS_VALU counts wave-instructions; a wave64 VALU op occupies a SIMD-32 for >= 2 cycles"}
 json.dump({"config": "scene 3 1920x1080 100spp 50b fp32, sorted schedule; mean per dispatch", "counters": sq},
           open(os.path.join(dst, "%s_pmc_sq_final.json" % tag), "w"), indent=1)
 print(json.dumps(sq.get("main", {}), indent=1))
 
-for name, out in (("path_stats.json", "path_stats.json"), ("scaling_estimate.jsonl", "scaling_estimate_single_gpu.jsonl"), ("accounting.jsonl", "accounting_by_age_class.jsonl")):
+for name, out in (("path_stats.json", "path_stats.json"), ("path_stats_scene1.json", "path_stats_scene1.json"), ("scaling_estimate.jsonl", "scaling_estimate_single_gpu.jsonl"), ("accounting.jsonl", "accounting_by_age_class.jsonl")):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, out)))
