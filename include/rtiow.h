@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RTIOW_ABI_VERSION 2
+#define RTIOW_ABI_VERSION 3
 
 #define RTIOW_E_BADARG   (-1)
 #define RTIOW_E_STATE    (-2)   /* call order violated (e.g. render before set_scene) */
@@ -108,6 +108,11 @@ typedef struct {
     uint64_t max_chain_prepass;  /* last rtiow_count_segments: the longest per-pixel chain of      */
     uint64_t max_chain_main;     /* segments in each launch (a pixel's samples are sequential: one
                                   * RNG stream, so no schedule finishes before its longest chain)  */
+    /* RTIOW_SCENE_GRID, last render (all 0 when the scene runs without a grid): */
+    int32_t  grid_nx, grid_nz;   /* cells along x and z                                           */
+    int32_t  grid_registered;    /* spheres binned into cells (each in up to 2 x 2 of them)       */
+    int32_t  grid_direct;        /* spheres every ray tests exactly (too big for a cell / overflow) */
+    double   grid_cell;          /* cell width                                                    */
 } rtiow_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------

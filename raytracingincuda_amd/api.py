@@ -65,7 +65,9 @@ class Stats(ctypes.Structure):
                 ("schedule", ctypes.c_int32), ("grid_blocks", ctypes.c_int32), ("phases", ctypes.c_int32),
                 ("prepass_samples", ctypes.c_int32), ("prepass_ms", ctypes.c_double), ("main_ms", ctypes.c_double),
                 ("segments_prepass", ctypes.c_uint64), ("segments_main", ctypes.c_uint64),
-                ("max_chain_prepass", ctypes.c_uint64), ("max_chain_main", ctypes.c_uint64)]
+                ("max_chain_prepass", ctypes.c_uint64), ("max_chain_main", ctypes.c_uint64),
+                ("grid_nx", ctypes.c_int32), ("grid_nz", ctypes.c_int32), ("grid_registered", ctypes.c_int32),
+                ("grid_direct", ctypes.c_int32), ("grid_cell", ctypes.c_double)]
 
 
 class GroupStats(ctypes.Structure):

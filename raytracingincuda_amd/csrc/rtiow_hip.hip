@@ -234,6 +234,14 @@ __device__ __forceinline__ const __attribute__((address_space(4))) GridParams& g
 
 #define RT_FMA(a, b, c) Real<T>::fma((a), (b), (c))
 
+// ---- double-execution probes (scripts/cost_probe.sh; compiled out by default).  With -DRTIOW_PROBE_<X> the
+// component X runs a SECOND time on copies of its inputs and the results are thrown away behind an opaque
+// asm, so the image is unchanged and the growth of SQ_INSTS_VALU is exactly what X costs.
+#define RT_KEEP1(v) asm volatile("" :: "v"(v))
+template <class T> __device__ __forceinline__ void rt_opaque(V3<T>& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z)); }
+__device__ __forceinline__ void rt_opaque(Rng& r) { asm volatile("" : "+v"(r.v0), "+v"(r.v1), "+v"(r.v2), "+v"(r.v3), "+v"(r.v4), "+v"(r.d)); }
+
+
 template <class T> __device__ __forceinline__ T dot3(V3<T> u, V3<T> v) {   // vec3.h:93-97
     return RT_FMA(u.z, v.z, RT_FMA(u.y, v.y, u.x * v.x));
 }
@@ -726,6 +734,16 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
         return;
     }
     REGION_BEGIN(direct);
+#ifdef RTIOW_PROBE_DIRECT
+    {
+        V3<T> o2 = O, d2 = D; rt_opaque(o2); rt_opaque(d2); T c2 = __builtin_huge_val(); int h2 = -1;
+        const T* dg = reinterpret_cast<const T*>(smem_raw + g.direct_offset);
+        const int* ids = reinterpret_cast<const int*>(smem_raw + g.direct_ids_offset);
+        const LoopRay<T> r = make_loop_ray(o2.x, o2.y, o2.z, d2.x, d2.y, d2.z, a);
+        for (int s = 0; s < g.n_direct_padded; s += 4) direct_trip<T>(dg, ids, s, r, c2, h2);
+        RT_KEEP1(c2); RT_KEEP1(h2);
+    }
+#endif
     // ---- the direct list: packed trips, every ray
     {
         const T* dg = reinterpret_cast<const T*>(smem_raw + g.direct_offset);
@@ -874,6 +892,9 @@ __device__ __forceinline__ bool shade_step(const RenderParams<T>& p, const T* ld
             nd = madd3(k, nrm, perp);
         }
     } else {
+#ifdef RTIOW_PROBE_RUV
+        { Rng c = st.rs; rt_opaque(c); V3<T> r2 = random_unit_vector<T>(c); RT_KEEP1(r2.x); RT_KEEP1(r2.y); RT_KEEP1(r2.z); RT_KEEP1(c.v4); }
+#endif
         const V3<T> ruv = random_unit_vector<T>(st.rs);
         if (mtype == RTIOW_LAMBERTIAN) {                                 // material.h:38-49
             nd = {nrm.x + ruv.x, nrm.y + ruv.y, nrm.z + ruv.z};
@@ -1126,6 +1147,7 @@ render_kernel(const RenderParams<T> p) {
     bool fresh = true;                            // the lane needs a primary ray (camera.h:141-155)
 
     while (st.sample < S) {
+        PATH_STAT(PS_ITERATION);
         if (fresh) { gen_primary(p, i, j, st.rs, st.O, st.D, st.sky_uy); st.atten = {1, 1, 1}; fresh = false; }
         V3<T> col;
         if (st.depth < p.B) { ++cost; if (COUNT) ++nseg; }
@@ -1250,6 +1272,9 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
         if (alive) PATH_STAT(PS_ITERATION);
         // one site generates every primary ray: first sample of a new pixel or the next sample
         REGION_BEGIN(gen);
+#ifdef RTIOW_PROBE_GEN
+        if (alive && fresh) { Rng c = st.rs; rt_opaque(c); V3<T> o2, d2; T u2; gen_primary(p, i, j, c, o2, d2, u2); RT_KEEP1(o2.x); RT_KEEP1(o2.y); RT_KEEP1(o2.z); RT_KEEP1(d2.x); RT_KEEP1(d2.y); RT_KEEP1(d2.z); RT_KEEP1(u2); RT_KEEP1(c.v4); }
+#endif
         if (alive && fresh) { gen_primary(p, i, j, st.rs, st.O, st.D, st.sky_uy); st.atten = {1, 1, 1}; fresh = false; }
         REGION_END(gen, RG_GEN_PRIMARY);
         bool terminated = false;
@@ -1276,11 +1301,17 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
             REGION_BEGIN(hw);
             if (need_hit) {
                 const T a = dot3(st.D, st.D);                 // hittable.h:43, ray-invariant
+#ifdef RTIOW_PROBE_HIT
+                { V3<T> o2 = st.O, d2 = st.D; rt_opaque(o2); rt_opaque(d2); T c2 = __builtin_huge_val(); int h2 = -1; hit_world<T, SRC>(p, lds_geom, o2, d2, dot3(d2, d2), c2, h2); RT_KEEP1(c2); RT_KEEP1(h2); }
+#endif
                 hit_world<T, SRC>(p, lds_geom, st.O, st.D, a, closest, hit);
             }
             REGION_END(hw, RG_HIT_WORLD);
         }
         REGION_BEGIN(shade);
+#ifdef RTIOW_PROBE_SHADE
+        if (alive && need_hit) { PathState<T> s2 = st; rt_opaque(s2.O); rt_opaque(s2.D); rt_opaque(s2.rs); V3<T> c2; const bool t2 = shade_step<T>(p, lds_shade, s2, closest, hit, c2); RT_KEEP1(c2.x); RT_KEEP1(c2.y); RT_KEEP1(c2.z); RT_KEEP1(s2.O.x); RT_KEEP1(s2.D.x); RT_KEEP1(s2.D.y); RT_KEEP1(s2.D.z); RT_KEEP1(s2.rs.v4); RT_KEEP1(s2.atten.x); RT_KEEP1((int)t2); }
+#endif
         if (alive) {
             if (need_hit) { ++cost; if (COUNT) ++nseg; }
             terminated = need_hit ? shade_step<T>(p, lds_shade, st, closest, hit, col) : true;   // camera.h:127 at the depth limit
@@ -1932,6 +1963,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     // the grid blob (cells | fp32 AoS table | direct table | direct ids) goes last
     p.grid = GridParams{};
     p.use_grid = 0;
+    if (!seg_counter) { h->stats.grid_nx = h->stats.grid_nz = h->stats.grid_registered = h->stats.grid_direct = 0; h->stats.grid_cell = 0; }
     if (lds_source && h->scene_source == RTIOW_SCENE_GRID && p.use_screen && h->grid.use_grid && lds + (size_t)h->grid.blob_bytes <= 160 * 1024) {
         p.grid = h->grid;
         p.grid.cells_offset = (int)lds;
@@ -1940,6 +1972,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         p.grid.direct_ids_offset = p.grid.direct_offset + h->grid_direct_bytes;
         lds += (size_t)h->grid.blob_bytes;
         p.use_grid = 1;
+        if (!seg_counter) { h->stats.grid_nx = h->grid.nx; h->stats.grid_nz = h->grid.nz; h->stats.grid_registered = h->grid_registered; h->stats.grid_direct = h->grid_direct; h->stats.grid_cell = h->grid.cell; }
     } else if (effective_source == RTIOW_SCENE_GRID) effective_source = RTIOW_SCENE_LDS;   // no grid for this scene: the screened loop
     if (lds > 160 * 1024) return fail_arg(h, RTIOW_E_BADARG, "scene too large for LDS staging; use RTIOW_SCENE_SCALAR");
     RenderFn<T> k = pick_kernel<T>(persistent, lds_source, seg_counter != nullptr);

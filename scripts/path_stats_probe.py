@@ -14,7 +14,8 @@ W, H, S, B = (int(x) for x in a[1:5]) if len(a) >= 5 else (1920, 1080, 100, 50)
 names = ["iteration", "ruv_call", "ruv_round", "disk_round", "gen_primary", "shade_hit", "sky", "dielectric", "metal",
          "exact_block", "finish_call", "ieee_block", "second_div", "schlick_draw", "refill", "finish_pixel", "grid_step"]
 r = rt.Renderer(0, 32); r.set_camera(rt.camera(32, W, H, S, B)); r.set_scene(rt.build_scene(scene, 32))
-r.init_rng(1227); r.set_schedule(rt.SCHED_SORTED, 0)
+sched = int(os.environ.get("RTIOW_PROBE_SCHED", "2"))
+r.init_rng(1227); r.set_schedule(sched, 0)
 lib = api.load_hip_library()
 buf = (ctypes.c_ulonglong * (2 * len(names)))()
 assert lib.rtiow_debug_path_stats(buf, len(buf), 1) == 0
@@ -26,7 +27,7 @@ assert lib.rtiow_debug_region_cycles(rbuf, len(rbuf), 0) == 0
 assert lib.rtiow_debug_path_stats(buf, len(buf), 0) == 0
 v = list(buf)
 it = float(v[0])
-out = {"config": "scene %d %dx%d %d spp %d bounces fp32, sorted schedule (prepass + main launch together)" % (scene, W, H, S, B), "wave_iterations": int(it),
+out = {"config": "scene %d %dx%d %d spp %d bounces fp32, schedule %d (all launches together)" % (scene, W, H, S, B, sched), "wave_iterations": int(it),
        "lanes_per_iteration": round(v[1] / it, 2), "per_wave_iteration": {}}
 for k, n in enumerate(names[1:], 1):
     out["per_wave_iteration"][n] = {"wave_executions": round(v[2 * k] / it, 3), "active_lanes_each": round(v[2 * k + 1] / max(v[2 * k], 1), 1)}

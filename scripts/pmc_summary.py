@@ -7,7 +7,7 @@ for d in sys.argv[1:]:
             k = r["Kernel_Name"]
             if "render_" not in k:
                 continue
-            k = k.split("render_")[1].split("(")[0][:28]
+            k = k.split("render_")[1].split("(")[0][:40]
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
-        print(json.dumps({"dir": d.split("/")[-1], "kernel": k, **{c: round(sum(x) / len(x)) for c, x in sorted(v.items())}}))
+        print(json.dumps({"dir": d.split("/")[-1], "kernel": k, "dispatches": len(next(iter(v.values()))), **{c: round(sum(x) / len(x)) for c, x in sorted(v.items())}}))

@@ -60,7 +60,7 @@ def _same_bits(a, b):
 def test_native_library_is_what_runs(rt):
     rt.load_host_library()
     with rt.Renderer(0, 32) as r:
-        assert r._lib.rtiow_abi_version() == 2
+        assert r._lib.rtiow_abi_version() == 3
     maps = open("/proc/self/maps").read()
     assert "librtiow_hip.so" in maps and "librtiow_host.so" in maps
 
@@ -347,7 +347,12 @@ def test_grid_walk_equals_exact_loop_on_the_reference_scenes(rt):
         sc = rt.build_scene(scene_id, prec)
         a, st = _custom(rt, prec, sc, W, H, S, 50, rt.SCENE_GRID)
         assert st["scene_source"] == rt.SCENE_GRID, (prec, scene_id)
+        # the ground and the three unit spheres are the direct list, every small sphere sits in a cell
+        assert st["grid_direct"] == 4 and st["grid_registered"] == st["num_spheres"] - 4 and 0.9 < st["grid_cell"] < 1.3, st
+        lo, hi = {1: (21, 25), 2: (6, 9), 3: (11, 14)}[scene_id]                  # the reference's own 22 / 6 / 11-cell grids, plus margins
+        assert lo <= st["grid_nx"] <= hi and lo <= st["grid_nz"] <= hi, st
         b, st_b = _custom(rt, prec, sc, W, H, S, 50, rt.SCENE_LDS_EXACT, sched=rt.SCHED_STATIC)
+        assert st_b["grid_nx"] == 0 and st_b["grid_direct"] == 0
         assert st_b["scene_source"] == rt.SCENE_LDS_EXACT
         assert _same_bits(a, b), (prec, scene_id)
         c, _ = _custom(rt, prec, sc, W, H, S, 50, rt.SCENE_LDS)
