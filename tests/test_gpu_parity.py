@@ -415,6 +415,32 @@ def test_grid_walk_equals_exact_loop_on_random_scenes(rt, oracle, case):
         assert _same_bits(got, want), (case, prec)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_grid_walk_equals_exact_loop_random_sweep(rt, seed):
+    """Ten more scenes drawn at random (count, extent, radius law, height spread, with or without the
+    ground and big spheres, scene centre on or off the camera axis): grid walk == exact loop, bit for
+    bit.  Whether a scene gets a grid at all is the builder's choice; at least the common ones must."""
+    rng = np.random.default_rng(1000 + seed)
+    prec = 32 if seed % 2 == 0 else 64
+    n = int(rng.integers(60, 700))
+    half = float(rng.uniform(3, 25))
+    cx, cz = (0.0, 0.0) if seed % 3 else (float(rng.uniform(-30, 5)), float(rng.uniform(-20, 10)))
+    rlaw = [lambda g: 0.2, lambda g: float(g.uniform(0.05, 0.5)), lambda g: float(g.choice([0.1, 0.35])), lambda g: float(np.exp(g.uniform(np.log(0.02), np.log(0.6))))][seed % 4]
+    yspread = float(rng.choice([0.0, 0.5, 3.0]))
+    big = [(cx, 1.0, cz, 1.0), (cx - 4.0, 1.0, cz, 1.0)] if seed % 2 else []
+    sc = _random_field(rng, prec, n, (cx - half, cx + half), (cz - half, cz + half), rlaw, lambda g, r: r + float(g.uniform(0, yspread)) if yspread else r,
+                       ground=seed % 5 != 4, big=big)
+    W, H, S, B = 200, 120, 4, 16
+    a, st = _custom(rt, prec, sc, W, H, S, B, rt.SCENE_GRID)
+    b, _ = _custom(rt, prec, sc, W, H, S, B, rt.SCENE_LDS_EXACT, sched=rt.SCHED_STATIC)
+    assert _same_bits(a, b), (seed, st)
+    c, _ = _custom(rt, prec, sc, W, H, S, B, rt.SCENE_GRID, sched=rt.SCHED_STATIC)
+    assert _same_bits(c, b), (seed, st)
+    print("seed %d: n=%d source=%d grid %dx%d registered %d direct %d" % (seed, n, st["scene_source"], st["grid_nx"], st["grid_nz"], st["grid_registered"], st["grid_direct"]))
+    if seed in (0, 2, 3, 5, 6, 7, 8):            # the other three are too dense for 4-entry cells and keep the screened loop
+        assert st["scene_source"] == rt.SCENE_GRID and st["grid_registered"] >= 16, (seed, st)
+
+
 def test_screen_equals_exact_on_the_488_sphere_scene(rt):
     """Scene 1 at 1280x720x20: the screened loop (default) vs the exact loop, bit for bit."""
     a = _render(rt, 32, 1, 1280, 720, 20, 50, threads=0, source=rt.SCENE_LDS)
