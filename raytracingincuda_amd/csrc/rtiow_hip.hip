@@ -1169,6 +1169,11 @@ render_kernel(const RenderParams<T> p) {
 // tile-major from the BOTTOM of the image up (ground and spheres first, cheap sky last) to
 // keep the drain tail short.  Per-pixel work and RNG streams are unchanged => same image.
 constexpr int POOL = 64;
+// Longest share of the brute-force sphere loop (trips of four spheres) for which the drain still splits it
+// among idle lanes instead of walking the grid (persistent_body).
+#ifndef RTIOW_COOP_MAX_TRIPS
+#define RTIOW_COOP_MAX_TRIPS 6
+#endif
 
 template <class T, int SRC, bool COUNT>
 __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
@@ -1283,11 +1288,20 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
         const bool need_hit = alive && st.depth < p.B;
         T closest = __builtin_huge_val();
         int hit = -1;
-        if ((exhausted || 2 * p.lane_cap <= wave_lanes) && 2 * __builtin_popcountll(alive_mask) <= wave_lanes) {
+        bool share_loops = (exhausted || 2 * p.lane_cap <= wave_lanes) && 2 * __builtin_popcountll(alive_mask) <= wave_lanes;
+        const unsigned long long hit_mask = __builtin_amdgcn_ballot_w64(need_hit);
+        if (share_loops && p.use_grid && hit_mask != 0) {
+            // With a grid, sharing the brute-force loop only pays while a ray's share of it is short: g lanes per
+            // ray leave it n_trips / g trips of ~38 instructions, the grid path costs ~300 whatever the lane count.
+            const int n_need = __builtin_popcountll(hit_mask);
+            int lg = 0;
+            while ((n_need << (lg + 1)) <= wave_lanes) ++lg;
+            share_loops = ((p.n_padded >> 2) + (1 << lg) - 1) >> lg <= RTIOW_COOP_MAX_TRIPS;
+        }
+        if (share_loops) {
             // drain tail: idle lanes share the survivors' sphere loops (hit_world_coop)
             if (COUNT) ++it_coop;
             REGION_BEGIN(coop);
-            const unsigned long long hit_mask = __builtin_amdgcn_ballot_w64(need_hit);
             if (hit_mask != 0) {
                 const T a = dot3(st.D, st.D);
                 if (sizeof(T) == 4 && wave_lanes == 64 && (hit_mask & (hit_mask - 1)) == 0)

@@ -7,8 +7,11 @@ ap.add_argument("--scene", type=int, default=3); ap.add_argument("--w", type=int
 ap.add_argument("--s", type=int, default=100); ap.add_argument("--b", type=int, default=50); ap.add_argument("--prec", type=int, default=32)
 ap.add_argument("--sched", type=int, default=1); ap.add_argument("--source", type=int, default=3); ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--reps", type=int, default=3); ap.add_argument("--wps", type=int, default=0)
+ap.add_argument("--shard", default="", help="rank,nranks,strip_rows")
 a = ap.parse_args()
 r = rt.Renderer(0, a.prec); r.set_camera(rt.camera(a.prec, a.w, a.h, a.s, a.b)); r.set_scene(rt.build_scene(a.scene, a.prec))
+if a.shard:
+    r.set_shard(*[int(x) for x in a.shard.split(",")])
 r.set_schedule(a.sched, a.wps); r.set_scene_source(a.source); r.init_rng(1227)
 print([round(r.render(a.threads), 3) for _ in range(a.reps)], r.stats())
 r.close()

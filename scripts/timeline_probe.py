@@ -12,10 +12,10 @@ def main(shard=None, lr=0, wps=0, threads=0, sched=2):
     tl = tl[tl[:, 2] > 0]
     t0 = tl[:, 0].min()
     start = (tl[:, 0] - t0) / 100.0; exh = np.where(tl[:, 1] > 0, (tl[:, 1] - t0) / 100.0, np.nan); end = (tl[:, 2] - t0) / 100.0   # us
-    q = lambda a: [round(float(x), 1) for x in np.nanpercentile(a, [0, 10, 50, 90, 99, 100])]
+    q = lambda a: [round(float(x), 1) for x in np.atleast_1d(np.nanpercentile(a, [0, 10, 50, 90, 99, 100]))] if np.size(a) and not np.all(np.isnan(a)) else []
     print(json.dumps({"shard": shard, "sched": sched, "wps": wps, "threads": threads, "render_ms": round(ms, 3), "waves": len(tl), "start_us": q(start), "exhausted_us": q(exh), "end_us": q(end),
                       "tail_us(end-exh)": q(end - exh), "iters_normal": q(tl[:, 3]), "iters_coop": q(tl[:, 4]), "pixels_per_wave": q(tl[:, 5]),
                       "us_per_normal_iter": q((np.nan_to_num(exh, nan=0) - start)[tl[:, 3] > 0] / tl[:, 3][tl[:, 3] > 0]),
                       "us_per_coop_iter": q(((end - exh)[tl[:, 4] > 0]) / tl[:, 4][tl[:, 4] > 0])}), flush=True)
     r.close()
-main(shard=(1, 4, 8)); main(shard=(3, 8, 8)); main(shard=(1, 4, 8), sched=1)
+main(); main(shard=(1, 2, 8)); main(shard=(1, 4, 2)); main(shard=(3, 8, 2))
