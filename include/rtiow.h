@@ -201,6 +201,14 @@ int rtiow_debug_ops(rtiow_handle h, int op, size_t n, const void* a, const void*
  * them: from its committed constant A^(2^67), or from_scratch != 0 from the one-step matrix A.
  * Host arithmetic only (no GPU needed).  Returns the number of matrices. */
 int rtiow_debug_jump_matrices(uint32_t* out_words, size_t cap_words, int from_scratch);
+/* The uniform-grid plan of RTIOW_SCENE_GRID for n spheres {cx,cy,cz,r} (doubles) around the recentring point
+ * centre3, as the library builds it.  Host arithmetic only (no GPU needed).  dims4 = {nx, nz, registered
+ * spheres, direct-list length}; params8 = {x0, z0, cell, slab ylo, slab yhi, Rfar, eps, Cmax}; cells (optional)
+ * = nx*nz*4 sphere indices (0xffff x4: empty cell, n: pad); direct (optional) = the direct list; halfwidth
+ * (optional, n entries) = registration half-width of every gridded sphere.  Returns 1 when the library would
+ * use the grid for this scene, 0 when it keeps the screened loop, negative on bad arguments. */
+int rtiow_debug_grid_plan(int n, const double* center_radius, const double* centre3, int32_t* dims4, double* params8,
+                          uint16_t* cells, size_t cells_cap, int32_t* direct, size_t direct_cap, double* halfwidth);
 
 /* ======================================================================================
  * Multi-GPU inside one process (new work: the reference is single-GPU, main.cu:81).

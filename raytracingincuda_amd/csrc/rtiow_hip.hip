@@ -1729,8 +1729,8 @@ int build_screen_table(rtiow_handle_s* h) {
     return 0;
 }
 
-// Builds the uniform grid of hit_world_grid for the current scene (after build_screen_table, whose
-// recentring point it shares).  On return h->grid.use_grid says whether the scene has one.
+// The plan of the uniform grid of hit_world_grid for a scene: pure host arithmetic (no GPU), shared by
+// build_grid_tables and the rtiow_debug_grid_plan test hook.
 //
 //  small sphere    : registration half-width w_i = sqrt(r_i^2 + E_i) + eps <= cell / 2, where
 //                    E_i = 18 * 2^-24 ((Rfar + Cmax)^2 + r_i^2) bounds the reference's discriminant
@@ -1739,21 +1739,25 @@ int build_screen_table(rtiow_handle_s* h) {
 //  registration    : sphere i goes into every cell its square [c - w, c + w]^2 touches (<= 2 x 2),
 //                    in index order; a sphere that meets a full cell (4 entries) joins the direct list;
 //  direct list     : everything else (ground, big spheres, overflow), tested exactly by every ray.
-// The scene keeps the screened loop when the grid would not pay (few small spheres, or a direct
-// list that is no shorter than a fraction of the scene).
-template <class T>
-int build_grid_tables(rtiow_handle_s* h) {
-    GridParams& g = h->grid;
-    g = GridParams{};
-    if (h->grid_blob) { HIP_TRY(h, hipFree(h->grid_blob)); h->grid_blob = nullptr; }
-    const int m = h->n;
-    const std::vector<double>& cr = h->host_cr;
-    if (m < 24 || m > 60000) return 0;
+// Candidate "small" sets: every finite sphere, then without the largest radii, and so on; each
+// candidate whose cells are at least as wide as its widest member is registered, and the plan with the
+// shortest direct list wins.  `usable` stays false when the grid would not pay (few small spheres,
+// or a direct list that is no shorter than a fraction of the scene): the scene keeps the screened loop.
+struct GridPlan {
+    bool usable = false;
+    int nx = 0, nz = 0, registered = 0;
+    float cellf = 0, x0f = 0, z0f = 0;
+    double rfar = 0, eps = 0, ylo = 1e300, yhi = -1e300, core_lo[3] = {1e300, 1e300, 1e300}, core_hi[3] = {-1e300, -1e300, -1e300}, rmax_g = 0, cmax_g = 0;
+    std::vector<uint16_t> cells;        // [nz][nx][4]: sphere indices, 0xffff x4 = empty cell, index m = never-hit pad
+    std::vector<int> direct;
+    std::vector<double> halfwidth;      // w_i of the registered spheres (0 for the direct list)
+};
+
+GridPlan plan_grid(int m, const std::vector<double>& cr, const double* ctr) {
+    GridPlan best;
+    if (m < 24 || m > 60000) return best;
     std::vector<double> radii(m);
     for (int i = 0; i < m; ++i) radii[i] = cr[4 * i + 3];
-    // Candidate "small" sets: every finite sphere, then without the largest radii, and so on.  Each
-    // candidate whose cells (one per sphere by area) are at least as wide as its widest member is
-    // registered; the plan with the shortest direct list wins.
     std::vector<int> small;
     for (int i = 0; i < m; ++i) {
         bool ok = radii[i] > 0 && std::isfinite(radii[i]);
@@ -1762,21 +1766,13 @@ int build_grid_tables(rtiow_handle_s* h) {
     }
     std::sort(small.begin(), small.end(), [&](int a, int b) { return radii[a] < radii[b] || (radii[a] == radii[b] && a < b); });
     const double u18 = 18.0 * std::ldexp(1.0, -24) * 1.01;
-    struct Plan {
-        int nx = 0, nz = 0, registered = 0;
-        float cellf = 0, x0f = 0, z0f = 0;
-        double rfar = 0, ylo = 1e300, yhi = -1e300, core_lo[3] = {1e300, 1e300, 1e300}, core_hi[3] = {-1e300, -1e300, -1e300}, rmax_g = 0, cmax_g = 0;
-        std::vector<uint16_t> cells;
-        std::vector<int> direct;
-    };
-    Plan best;
     bool have = false;
     std::vector<double> w(m, 0.0);
     for (int attempt = 0; attempt < 12 && (int)small.size() >= 16; ++attempt) {
         double cmax = 0, lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, rmax = 0;
         for (int i : small) {
             double d2 = 0;
-            for (int k = 0; k < 3; ++k) { const double d = cr[4 * i + k] - h->ctr[k]; d2 += d * d; lo[k] = std::min(lo[k], cr[4 * i + k]); hi[k] = std::max(hi[k], cr[4 * i + k]); }
+            for (int k = 0; k < 3; ++k) { const double d = cr[4 * i + k] - ctr[k]; d2 += d * d; lo[k] = std::min(lo[k], cr[4 * i + k]); hi[k] = std::max(hi[k], cr[4 * i + k]); }
             cmax = std::max(cmax, std::sqrt(d2));
             rmax = std::max(rmax, radii[i]);
         }
@@ -1784,7 +1780,7 @@ int build_grid_tables(rtiow_handle_s* h) {
         cmax *= 1.0001;
         const double rfar = std::max(64.0, 4.0 * cmax);
         double cabs = 0;
-        for (int k = 0; k < 3; ++k) cabs = std::max(cabs, std::fabs(h->ctr[k]));
+        for (int k = 0; k < 3; ++k) cabs = std::max(cabs, std::fabs(ctr[k]));
         const double L = 2.0 * (rfar + cmax) + cabs + rmax;            // every coordinate the walk handles is smaller
         const double eps = std::ldexp(L, -16);
         double wmax = 0;
@@ -1795,20 +1791,20 @@ int build_grid_tables(rtiow_handle_s* h) {
         }
         const double ext_x = (hi[0] - lo[0]) + 2 * wmax, ext_z = (hi[2] - lo[2]) + 2 * wmax;
         double cell = std::sqrt(ext_x * ext_z / (double)small.size());
-        const bool usable = L < 1e6 && cell >= 2.0 * (wmax + eps) * 1.02;
-        if (usable) {
-            Plan pl;
+        if (L < 1e6 && cell >= 2.0 * (wmax + eps) * 1.02) {
+            GridPlan pl;
             for (;;) {
                 pl.nx = (int)std::ceil(ext_x / cell) + 1; pl.nz = (int)std::ceil(ext_z / cell) + 1;
                 if ((long long)pl.nx * pl.nz <= 4096) break;
                 cell *= 1.25;
             }
-            pl.cellf = (float)cell; pl.rfar = rfar;
+            pl.cellf = (float)cell; pl.rfar = rfar; pl.eps = eps;
             pl.x0f = (float)(lo[0] - wmax - 0.25 * cell); pl.z0f = (float)(lo[2] - wmax - 0.25 * cell);
             // registration against the cell edges the KERNEL will use (fp32 origin and width), widened by eps again
             auto cell_of = [&](double v, float origin) { return (int)std::floor((v - (double)origin) / (double)pl.cellf); };
             const int nx = pl.nx, nz = pl.nz;
             pl.cells.assign((size_t)nx * nz * 4, 0xffff);
+            pl.halfwidth.assign(m, 0.0);
             std::vector<int> count((size_t)nx * nz, 0);
             std::vector<char> is_small(m, 0);
             for (int i : small) is_small[i] = 1;
@@ -1824,10 +1820,11 @@ int build_grid_tables(rtiow_handle_s* h) {
                 for (int iz = iz0; iz <= iz1; ++iz)
                     for (int ix = ix0; ix <= ix1; ++ix) { const size_t c = (size_t)iz * nx + ix; pl.cells[4 * c + count[c]++] = (uint16_t)i; }
                 ++pl.registered;
+                pl.halfwidth[i] = w[i];
                 pl.ylo = std::min(pl.ylo, cy - w[i]); pl.yhi = std::max(pl.yhi, cy + w[i]);
                 const double c3[3] = {cx, cy, cz};
                 double d2 = 0;
-                for (int k = 0; k < 3; ++k) { pl.core_lo[k] = std::min(pl.core_lo[k], c3[k]); pl.core_hi[k] = std::max(pl.core_hi[k], c3[k]); const double d = c3[k] - h->ctr[k]; d2 += d * d; }
+                for (int k = 0; k < 3; ++k) { pl.core_lo[k] = std::min(pl.core_lo[k], c3[k]); pl.core_hi[k] = std::max(pl.core_hi[k], c3[k]); const double d = c3[k] - ctr[k]; d2 += d * d; }
                 pl.rmax_g = std::max(pl.rmax_g, radii[i]);
                 pl.cmax_g = std::max(pl.cmax_g, std::sqrt(d2));
             }
@@ -1838,7 +1835,21 @@ int build_grid_tables(rtiow_handle_s* h) {
         }
         while (!small.empty() && radii[small.back()] >= cut) small.pop_back();
     }
-    if (!have || (int)best.direct.size() > std::max(8, m / 6)) return 0;
+    best.usable = have && (int)best.direct.size() <= std::max(8, m / 6);
+    return best;
+}
+
+// Builds the device tables of hit_world_grid for the current scene (after build_screen_table, whose
+// recentring point the plan shares).  On return h->grid.use_grid says whether the scene has a grid.
+template <class T>
+int build_grid_tables(rtiow_handle_s* h) {
+    GridParams& g = h->grid;
+    g = GridParams{};
+    if (h->grid_blob) { HIP_TRY(h, hipFree(h->grid_blob)); h->grid_blob = nullptr; }
+    const int m = h->n;
+    const std::vector<double>& cr = h->host_cr;
+    const GridPlan best = plan_grid(m, cr, h->ctr);
+    if (!best.usable) return 0;
     const std::vector<uint16_t>& cells = best.cells;
     const std::vector<int>& direct = best.direct;
     const int nx = best.nx, nz = best.nz, registered = best.registered;
@@ -2513,6 +2524,19 @@ int rtiow_debug_timeline(rtiow_handle h, int threads_per_block_row, uint64_t* ou
     const size_t words = nw * 8 < cap_words ? nw * 8 : cap_words;
     HIP_TRY(h, hipMemcpy(out_words, buf.ptr, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
+}
+
+int rtiow_debug_grid_plan(int n, const double* center_radius, const double* centre3, int32_t* dims4, double* params8,
+                          uint16_t* cells, size_t cells_cap, int32_t* direct, size_t direct_cap, double* halfwidth) {
+    if (n <= 0 || !center_radius || !centre3 || !dims4 || !params8) return RTIOW_E_BADARG;
+    const std::vector<double> cr(center_radius, center_radius + 4 * (size_t)n);
+    const GridPlan pl = plan_grid(n, cr, centre3);                                   // host only, no GPU needed
+    dims4[0] = pl.nx; dims4[1] = pl.nz; dims4[2] = pl.registered; dims4[3] = (int)pl.direct.size();
+    params8[0] = pl.x0f; params8[1] = pl.z0f; params8[2] = pl.cellf; params8[3] = pl.ylo; params8[4] = pl.yhi; params8[5] = pl.rfar; params8[6] = pl.eps; params8[7] = pl.cmax_g;
+    if (cells) { if (cells_cap < pl.cells.size()) return RTIOW_E_BADARG; std::copy(pl.cells.begin(), pl.cells.end(), cells); }
+    if (direct) { if (direct_cap < pl.direct.size()) return RTIOW_E_BADARG; std::copy(pl.direct.begin(), pl.direct.end(), direct); }
+    if (halfwidth && !pl.halfwidth.empty()) std::copy(pl.halfwidth.begin(), pl.halfwidth.end(), halfwidth);
+    return pl.usable ? 1 : 0;
 }
 
 int rtiow_debug_jump_matrices(uint32_t* out_words, size_t cap_words, int from_scratch) {
