@@ -379,7 +379,7 @@ __device__ __forceinline__ bool root_pretest_rejects(T h, T disc, T a, T closest
     const T e = RT_FMA(kappa, Real<T>::fabs(h) + sq_approx, (T)8.673617379884035e-19);   // + 2^-60
     const T behind_bound = (tmin * a) * (T)0.99999904632568359375;  // tmin*a*(1-2^-20)
     const T far_bound = (closest * a) * (T)1.00000095367431640625; // closest*a*(1+2^-20); inf while nothing is hit
-    return ((h + sq_approx) + e < behind_bound) || ((h - sq_approx) - e > far_bound);
+    return (int)((h + sq_approx) + e < behind_bound) | (int)((h - sq_approx) - e > far_bound);   // one branch, not two
 }
 
 template <class T, bool ANYORDER = false>
@@ -637,13 +637,11 @@ __device__ __forceinline__ void hit_world_screened(const RenderParams<T>& p, con
 template <class T>
 __device__ __forceinline__ void direct_trip(const T* g, const int* ids, int s, const LoopRay<T>& r, T& closest, int& hit) {
     const Trip<T> t = trip_discriminants(g, s, r);
-    const T m = Real<T>::fmax(Real<T>::fmax(t.d0, t.d1), Real<T>::fmax(t.d2, t.d3));
-    if (m >= (T)0) {
-        if (t.d0 >= (T)0) finish_sphere_test<T, true>(ids[s + 0], t.h0, t.d0, r.a, closest, hit);
-        if (t.d1 >= (T)0) finish_sphere_test<T, true>(ids[s + 1], t.h1, t.d1, r.a, closest, hit);
-        if (t.d2 >= (T)0) finish_sphere_test<T, true>(ids[s + 2], t.h2, t.d2, r.a, closest, hit);
-        if (t.d3 >= (T)0) finish_sphere_test<T, true>(ids[s + 3], t.h3, t.d3, r.a, closest, hit);
-    }
+    // no common guard: some lane has a candidate on the direct list (the ground) in nearly every trip
+    if (t.d0 >= (T)0) finish_sphere_test<T, true>(ids[s + 0], t.h0, t.d0, r.a, closest, hit);
+    if (t.d1 >= (T)0) finish_sphere_test<T, true>(ids[s + 1], t.h1, t.d1, r.a, closest, hit);
+    if (t.d2 >= (T)0) finish_sphere_test<T, true>(ids[s + 2], t.h2, t.d2, r.a, closest, hit);
+    if (t.d3 >= (T)0) finish_sphere_test<T, true>(ids[s + 3], t.h3, t.d3, r.a, closest, hit);
 }
 
 // {cx, cy, cz, r*r} of sphere i for the per-lane gathers of the walk: fp32 from the AoS copy in the
