@@ -2025,7 +2025,10 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         int lane_cap = 64;
         {
             const long long pools = tile_slots / POOL, waves = (long long)h->num_cus * per_cu * waves_per_block;
-            while (lane_cap > 8 && pools * (64 / lane_cap) < waves) lane_cap >>= 1;   // the largest share that keeps every wave busy
+            while (lane_cap > 16 && pools * (64 / lane_cap) < waves) lane_cap >>= 1;  // the largest share that keeps every wave busy; not below 16 (with the grid walk 8-lane waves lose: scene 1 320x192x100 6.85 vs 5.96 ms, profiles/r02_lane_cap_sweep.jsonl)
+#ifdef RTIOW_TUNING
+            if (const char* e = std::getenv("RTIOW_TUNE_LANE_CAP")) lane_cap = std::atoi(e);
+#endif
         }
         p.lane_cap = lane_cap;
         long long blocks = (long long)h->num_cus * per_cu;

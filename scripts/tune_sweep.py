@@ -5,11 +5,13 @@ import numpy as np
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = os.path.join(root, "raytracingincuda_amd", "lib", "ab", "tuning.so")
 extra = sys.argv[1:]
-cases = [("default", {})] + [("SA=%d,deal=%d" % (sa, d), {"RTIOW_TUNE_SA": str(sa), "RTIOW_TUNE_DEAL": str(d)}) for sa in (3, 4, 6, 8) for d in (32, 64)]
+cases = [("default", {})] + [("lane_cap=%d" % c, {"RTIOW_TUNE_LANE_CAP": str(c)}) for c in (8, 16, 32, 64)] + [("lane_cap=%d,wps=%d" % (c, w), {"RTIOW_TUNE_LANE_CAP": str(c), "RTIOW_TUNE_WPS": str(w)}) for c in (32, 64) for w in (1, 2)]
 times = {c[0]: [] for c in cases}
 for rd in range(2):
     for name, env in cases:
-        out = subprocess.run([sys.executable, os.path.join(root, "scripts", "one_render.py"), "--sched", "2", "--reps", "6", *extra],
+        env = dict(env)
+        wps = ["--wps", env.pop("RTIOW_TUNE_WPS")] if "RTIOW_TUNE_WPS" in env else []
+        out = subprocess.run([sys.executable, os.path.join(root, "scripts", "one_render.py"), "--sched", "2", "--reps", "6", *extra, *wps],
                              env=dict(os.environ, RTIOW_HIP_LIBRARY=lib, **env), capture_output=True, text=True)
         if out.returncode != 0:
             print(name, "FAILED", out.stderr[-400:]); sys.exit(1)
