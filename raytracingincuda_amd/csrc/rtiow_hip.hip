@@ -15,6 +15,10 @@
 //  * sphere geometry {cx,cy,cz,r^2} is staged into LDS once per workgroup (or read with
 //    wave-uniform scalar loads, RTIOW_SCENE_SCALAR); per-ray invariants (|d|^2) are hoisted;
 //    the loop keeps only (t, index) of the nearest hit and completes the hit record once;
+//  * hit_world (default RTIOW_SCENE_GRID): a lane walks the cells of a uniform grid over the small
+//    spheres that ITS ray crosses and tests only their spheres, plus a short direct list (ground,
+//    big spheres) -- exact, see hit_world_grid; the brute-force loop with its packed-fp32 screen
+//    (hit_world_screened) remains for scenes without a grid, far rays and the cooperative drain;
 //  * per-pixel XORWOW streams (curand_init(1227, global_pixel_index, 0) semantics) are
 //    created by a separate untimed kernel and read as SoA; they are not written back;
 //  * no MFMA: this is branchy scalar FP, not a contraction.
