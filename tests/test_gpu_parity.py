@@ -441,6 +441,71 @@ def test_grid_walk_equals_exact_loop_random_sweep(rt, seed):
         assert st["scene_source"] == rt.SCENE_GRID and st["grid_registered"] >= 16, (seed, st)
 
 
+def _crafted_camera(rt, prec, W, H, S, B, center, direction, spread=0.0):
+    """A camera whose primary rays all leave `center` along `direction` (pixel deltas `spread` x unit steps in the plane
+    across it; 0 = every ray identical), no defocus: the degenerate rays a perspective view never produces exactly."""
+    cam = rt.camera(prec, W, H, S, B)
+    d = np.array(direction, np.float64)
+    c = np.array(center, np.float64)
+    u = np.cross(d, [0.0, 1.0, 0.0]) if abs(d[1]) < 0.9 * np.linalg.norm(d) else np.cross(d, [1.0, 0.0, 0.0])
+    u = u / np.linalg.norm(u) * spread
+    v = np.cross(d, u); v = v / (np.linalg.norm(v) or 1.0) * spread
+    for k in range(3):
+        cam.center[k] = c[k]; cam.pixel00_loc[k] = c[k] + d[k] - (W // 2) * u[k] - (H // 2) * v[k]
+        cam.pixel_delta_u[k] = u[k]; cam.pixel_delta_v[k] = v[k]
+        cam.defocus_disk_u[k] = 0.0; cam.defocus_disk_v[k] = 0.0
+    cam.defocus_angle = 0.0
+    return cam
+
+
+def _render_cam(rt, prec, scene, cam, source, sched=2):
+    with rt.Renderer(0, prec) as r:
+        r.set_camera(cam); r.set_scene(scene); r.set_scene_source(source); r.set_schedule(sched); r.init_rng(1227)
+        r.render(0)
+        return r.read_framebuffer(), r.stats()
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+def test_grid_walk_on_degenerate_rays(rt, oracle, prec):
+    """Rays a perspective camera never produces exactly: parallel to a grid axis (zero direction components: the
+    clip's parallel case, a DDA that never steps on one axis), straight down and up, exactly diagonal (both
+    boundary crossings tie at every step), starting exactly ON a cell boundary and running along it, starting
+    inside a sphere, and far outside the scene looking in.  Every pixel gets the same primary ray (zero pixel
+    deltas, no defocus) and its own random stream, so the bounces differ.  Grid == exact loop, and == oracle."""
+    from tests.test_grid_plan import _plan
+    sc = rt.build_scene(3, prec)
+    keep = sc["valid"] != 0
+    pl = _plan(rt, sc["center_radius"][keep].astype(np.float64))
+    assert pl["usable"]
+    x0, z0, cell = float(np.float32(pl["x0"])), float(np.float32(pl["z0"])), float(np.float32(pl["cell"]))
+    first = sc["center_radius"][keep][1].astype(np.float64)                  # a small sphere
+    W, H, S, B = 32, 8, 6, 12
+    cases = [((20.0, 0.2, first[2]), (-1.0, 0.0, 0.0)),                       # along -x through a row of spheres, inside the slab
+             ((first[0], 0.2, -30.0), (0.0, 0.0, 1.0)),                       # along +z
+             ((first[0], 5.0, first[2]), (0.0, -1.0, 0.0)),                   # straight down onto a sphere
+             ((first[0], 0.2, first[2]), (0.0, 1.0, 0.0)),                    # straight up from a sphere's centre (origin inside it)
+             ((-12.0, 0.2, -12.0), (1.0, 0.0, 1.0)),                          # exactly diagonal: tx == tz at every cell
+             ((x0 + 3 * cell, 0.2, 10.0), (0.0, 0.0, -1.0)),                  # on a cell boundary, along it
+             ((x0 + 3 * cell, 0.25, z0 + 2 * cell), (1.0, 0.0, -1.0)),        # from a cell corner, diagonally
+             ((300.0, 0.2, -5.5), (-1.0, 0.0, 0.0)),                          # a far origin skimming the field (fallback loop)
+             ((300.0, 40.0, -5.5), (-1.0, 0.0, 0.0)),                         # a far origin passing over it (no walk, no fallback)
+             ((-5.5, 0.2, -5.5), (1e-30, -1.0, 1e-30))]                       # denormal-small components
+    for center, direction in cases:
+        cam = _crafted_camera(rt, prec, W, H, S, B, center, direction)
+        a, st = _render_cam(rt, prec, sc, cam, rt.SCENE_GRID)
+        assert st["scene_source"] == rt.SCENE_GRID
+        b, _ = _render_cam(rt, prec, sc, cam, rt.SCENE_LDS_EXACT, sched=rt.SCHED_STATIC)
+        assert _same_bits(a, b), (center, direction)
+        want, _ = oracle.render(prec, compact(sc), cam, 1227)
+        assert _same_bits(a, want), (center, direction)
+    # the same views with a little spread (nearly axis-parallel bundles)
+    for center, direction in cases[:5]:
+        cam = _crafted_camera(rt, prec, 64, 32, 4, 12, center, direction, spread=1e-4)
+        a, _ = _render_cam(rt, prec, sc, cam, rt.SCENE_GRID)
+        b, _ = _render_cam(rt, prec, sc, cam, rt.SCENE_LDS_EXACT, sched=rt.SCHED_STATIC)
+        assert _same_bits(a, b), (center, direction, "spread")
+
+
 def test_screen_equals_exact_on_the_488_sphere_scene(rt):
     """Scene 1 at 1280x720x20: the screened loop (default) vs the exact loop, bit for bit."""
     a = _render(rt, 32, 1, 1280, 720, 20, 50, threads=0, source=rt.SCENE_LDS)
