@@ -197,6 +197,10 @@ int rtiow_debug_read_rng(rtiow_handle h, uint32_t* host_states, size_t count_wor
  * pixels taken, 0, 0}. */
 int rtiow_debug_timeline(rtiow_handle h, int threads_per_block_row, uint64_t* out_words, size_t cap_words, int* waves);
 int rtiow_debug_ops(rtiow_handle h, int op, size_t n, const void* a, const void* b, const void* c, void* out);
+/* hit_world (hittable.h:80-98) alone, with the handle's scene and scene source, on n caller-supplied rays
+ * {ox,oy,oz,dx,dy,dz} in the handle's precision: nearest root (+inf: none) and sphere index (-1: none) per ray.
+ * Lets the tests compare the scene sources on rays no render produces. */
+int rtiow_debug_hit_world(rtiow_handle h, int n, const void* rays, void* t_out, int32_t* index_out);
 /* The 32 XORWOW subsequence-jump matrices A^(2^(67+b)) (160 x 5 words each) as the library builds
  * them: from its committed constant A^(2^67), or from_scratch != 0 from the one-step matrix A.
  * Host arithmetic only (no GPU needed).  Returns the number of matrices. */

@@ -82,7 +82,7 @@ HIP_SYMBOLS = [
     "rtiow_set_scene", "rtiow_set_camera", "rtiow_set_shard", "rtiow_local_rows", "rtiow_local_row_map",
     "rtiow_init_rng", "rtiow_render", "rtiow_count_segments", "rtiow_bind_framebuffer", "rtiow_framebuffer_device_ptr",
     "rtiow_read_framebuffer", "rtiow_set_scene_source", "rtiow_set_schedule", "rtiow_get_stats", "rtiow_synchronize",
-    "rtiow_debug_read_rng", "rtiow_debug_timeline", "rtiow_debug_ops", "rtiow_debug_jump_matrices", "rtiow_debug_grid_plan",
+    "rtiow_debug_read_rng", "rtiow_debug_timeline", "rtiow_debug_ops", "rtiow_debug_jump_matrices", "rtiow_debug_grid_plan", "rtiow_debug_hit_world",
     "rtiow_render_async", "rtiow_render_wait", "rtiow_stream", "rtiow_device",
     "rtiow_group_create", "rtiow_group_create_error", "rtiow_group_destroy", "rtiow_group_last_error_string", "rtiow_group_size", "rtiow_group_member",
     "rtiow_group_set_scene", "rtiow_group_set_camera", "rtiow_group_set_scene_source", "rtiow_group_set_schedule",
@@ -364,6 +364,16 @@ class Renderer:
 
     def set_scene_source(self, source):
         self._check(self._lib.rtiow_set_scene_source(self._h, source))
+
+    def debug_hit_world(self, rays):
+        """hit_world alone on rays [n, 6] = {origin, direction}: (t [n], sphere index [n])."""
+        dt = _dtype(self.precision)
+        rays = np.ascontiguousarray(rays, dt)
+        n = rays.shape[0]
+        t = np.zeros(n, dt); idx = np.zeros(n, np.int32)
+        self._lib.rtiow_debug_hit_world.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self._check(self._lib.rtiow_debug_hit_world(self._h, n, rays.ctypes.data, t.ctypes.data, idx.ctypes.data))
+        return t, idx
 
     def set_schedule(self, schedule, waves_per_simd=0):
         self._check(self._lib.rtiow_set_schedule(self._h, schedule, waves_per_simd))

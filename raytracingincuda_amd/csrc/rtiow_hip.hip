@@ -1386,6 +1386,24 @@ __global__ void debug_ops_kernel(int op, size_t n, const T* a, const T* b, const
     }
 }
 
+// hit_world alone on caller-supplied rays, one per lane (rtiow_debug_hit_world): the tests feed it rays a
+// render never produces and compare the scene sources ray by ray.
+template <class T>
+__global__ void __launch_bounds__(256) hit_probe_kernel(const RenderParams<T> p, const T* __restrict__ rays, int n, T* __restrict__ out_t, int* __restrict__ out_idx) {
+    const T* lds_geom = stage_scene<T, RTIOW_SCENE_LDS>(p);
+    for (int base = (int)blockIdx.x * (int)blockDim.x; base < n; base += (int)gridDim.x * (int)blockDim.x) {
+        const int k = base + (int)threadIdx.x;
+        if (k < n) {
+            const V3<T> O = {rays[6 * (size_t)k], rays[6 * (size_t)k + 1], rays[6 * (size_t)k + 2]};
+            const V3<T> D = {rays[6 * (size_t)k + 3], rays[6 * (size_t)k + 4], rays[6 * (size_t)k + 5]};
+            T closest = __builtin_huge_val();
+            int hit = -1;
+            hit_world<T, RTIOW_SCENE_LDS>(p, lds_geom, O, D, dot3(D, D), closest, hit);
+            out_t[k] = closest; out_idx[k] = hit;
+        }
+    }
+}
+
 // ---- SCHED_SORTED: counting sort of the pixels by the cost measured in the prepass, heavy first,
 // dealt into balanced pools.  Sorted rank r -> slot: ranks are cut into blocks of
 // `pools_per_block` pools (the resident waves of one dispatch-age class); inside a block groups of
@@ -1571,6 +1589,7 @@ struct rtiow_handle_s {
     size_t timeline_cap_waves = 0;            // waves the debug timeline buffer holds
     unsigned int* work_counter = nullptr;
     unsigned long long* timeline = nullptr;   // debug: set only during rtiow_debug_timeline
+    int probe_n = 0; const void* probe_rays = nullptr; void* probe_t = nullptr; int* probe_idx = nullptr;   // debug: set only during rtiow_debug_hit_world
     rtiow_stats stats{};
 };
 
@@ -2002,6 +2021,15 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         if (!seg_counter) { h->stats.grid_nx = h->grid.nx; h->stats.grid_nz = h->grid.nz; h->stats.grid_registered = h->grid_registered; h->stats.grid_direct = h->grid_direct; h->stats.grid_cell = h->grid.cell; }
     } else if (effective_source == RTIOW_SCENE_GRID) effective_source = RTIOW_SCENE_LDS;   // no grid for this scene: the screened loop
     if (lds > 160 * 1024) return fail_arg(h, RTIOW_E_BADARG, "scene too large for LDS staging; use RTIOW_SCENE_SCALAR");
+    if (h->probe_n > 0) {                                    // rtiow_debug_hit_world: the tables are laid out, run hit_world on the caller's rays
+        if (!lds_source) return fail_arg(h, RTIOW_E_STATE, "rtiow_debug_hit_world needs an LDS scene source");
+        if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)hit_probe_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int blocks = std::min(2048, (h->probe_n + 255) / 256);
+        hipLaunchKernelGGL(hit_probe_kernel<T>, dim3(blocks), dim3(256), lds, h->stream, p, (const T*)h->probe_rays, h->probe_n, (T*)h->probe_t, h->probe_idx);
+        HIP_TRY(h, hipGetLastError());
+        if (!seg_counter) h->stats.scene_source = effective_source;
+        return 0;
+    }
     RenderFn<T> k = pick_kernel<T>(persistent, lds_source, seg_counter != nullptr);
     if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipFuncAttributes fa{};
@@ -2528,6 +2556,27 @@ int rtiow_debug_timeline(rtiow_handle h, int threads_per_block_row, uint64_t* ou
     *waves = (int)nw;
     const size_t words = nw * 8 < cap_words ? nw * 8 : cap_words;
     HIP_TRY(h, hipMemcpy(out_words, buf.ptr, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rtiow_debug_hit_world(rtiow_handle h, int n, const void* rays, void* t_out, int32_t* index_out) {
+    if (!h || n <= 0 || !rays || !t_out || !index_out) return RTIOW_E_BADARG;
+    if (!h->have_camera || h->n == 0) return fail_arg(h, RTIOW_E_STATE, "rtiow_debug_hit_world before rtiow_set_scene/rtiow_set_camera");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t es = elem_size(h);
+    DeviceScratch dr, dt, di;
+    HIP_TRY(h, dr.alloc((size_t)n * 6 * es)); HIP_TRY(h, dt.alloc((size_t)n * es)); HIP_TRY(h, di.alloc((size_t)n * sizeof(int)));
+    HIP_TRY(h, hipMemcpy(dr.ptr, rays, (size_t)n * 6 * es, hipMemcpyHostToDevice));
+    h->probe_n = n; h->probe_rays = dr.ptr; h->probe_t = dt.ptr; h->probe_idx = (int*)di.ptr;
+    const int saved_schedule = h->schedule;
+    h->schedule = RTIOW_SCHED_PERSISTENT;                    // table layout of the dynamic schedules (four-wave workgroups)
+    int rc = h->precision == 32 ? launch_render<float>(h, h->cam32, 16, 16, 1) : launch_render<double>(h, h->cam64, 16, 16, 1);
+    h->schedule = saved_schedule;
+    h->probe_n = 0; h->probe_rays = nullptr; h->probe_t = nullptr; h->probe_idx = nullptr;
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(t_out, dt.ptr, (size_t)n * es, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(index_out, di.ptr, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     return 0;
 }
 

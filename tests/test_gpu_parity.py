@@ -506,6 +506,77 @@ def test_grid_walk_on_degenerate_rays(rt, oracle, prec):
         assert _same_bits(a, b), (center, direction, "spread")
 
 
+def _adversarial_rays(rng, cr, plan, n_each):
+    """Ray families a render rarely or never produces, around the grid of `plan` (tests/test_grid_plan._plan)."""
+    x0, z0, cell, nx, nz = plan["x0"], plan["z0"], plan["cell"], plan["nx"], plan["nz"]
+    xs, zs = (x0, x0 + nx * cell), (z0, z0 + nz * cell)
+    def unit(n):
+        v = rng.normal(size=(n, 3)); return v / np.linalg.norm(v, axis=1, keepdims=True)
+    fam = []
+    # a. anywhere in and around the field, any direction, any length
+    o = np.column_stack([rng.uniform(xs[0] - 3, xs[1] + 3, n_each), rng.uniform(-0.5, 4, n_each), rng.uniform(zs[0] - 3, zs[1] + 3, n_each)])
+    fam.append(np.hstack([o, unit(n_each) * np.exp(rng.uniform(-3, 3, (n_each, 1)))]))
+    # b. from the ground plane, grazing
+    o = np.column_stack([rng.uniform(xs[0] - 20, xs[1] + 20, n_each), rng.choice([0.0, 1e-4, -1e-4], n_each), rng.uniform(zs[0] - 20, zs[1] + 20, n_each)])
+    d = unit(n_each); d[:, 1] = rng.choice([0.0, 1e-6, -1e-6, 1e-3, 0.02], n_each) * rng.choice([1, 1, 1, -1], n_each)
+    fam.append(np.hstack([o, d]))
+    # c. on cell boundaries and corners, axis-parallel, diagonal and random directions
+    o = np.column_stack([x0 + rng.integers(0, nx + 1, n_each) * cell, rng.uniform(0, 0.45, n_each), z0 + rng.integers(0, nz + 1, n_each) * cell])
+    o[: n_each // 2, 2] = rng.uniform(zs[0], zs[1], n_each // 2)                        # half of them on an x boundary only
+    axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 0, 1], [0, 0, -1], [1, 0, 1], [1, 0, -1], [-1, 0, 1], [-1, 0, -1], [0, 1, 0], [0, -1, 0]], np.float64)
+    d = np.where(rng.random((n_each, 1)) < 0.6, axes[rng.integers(0, len(axes), n_each)], unit(n_each))
+    fam.append(np.hstack([o, d]))
+    # d. far origins: aimed at the field (the brute-force fallback), past it, and away from it
+    far = unit(n_each) * np.exp(rng.uniform(np.log(50), np.log(5000), (n_each, 1))); far[:, 1] = np.abs(far[:, 1]) * rng.choice([1.0, 1e-3, 0.0], n_each)
+    centre = np.array([(xs[0] + xs[1]) / 2, 0.2, (zs[0] + zs[1]) / 2])
+    tgt = centre + np.column_stack([rng.uniform(-1, 1, n_each) * (xs[1] - xs[0]), rng.choice([0.0, 0.2, 3.0, 50.0], n_each), rng.uniform(-1, 1, n_each) * (zs[1] - zs[0])])
+    fam.append(np.hstack([centre + far, (tgt - centre - far) * rng.choice([1.0, -1.0], (n_each, 1), p=[0.85, 0.15])]))
+    # e. on sphere surfaces: outward, inward, tangent (self-intersection against tmin)
+    k = rng.integers(0, len(cr), n_each)
+    nrm = unit(n_each)
+    o = cr[k, :3] + nrm * cr[k, 3:4] * rng.choice([1.0, 1.0 + 1e-6, 1.0 - 1e-6, 0.5], (n_each, 1))
+    tang = np.cross(nrm, unit(n_each))
+    d = np.where(rng.random((n_each, 1)) < 0.4, tang, nrm * rng.choice([1.0, -1.0], (n_each, 1)) + 0.3 * unit(n_each))
+    fam.append(np.hstack([o, d]))
+    # f. degenerate numbers
+    r = fam[0][: n_each // 4].copy()
+    r[:, 3:] *= rng.choice([1e-25, 1e-12, 1e12, 1e25], (len(r), 1))
+    z = fam[0][: 64].copy(); z[:, 3:] = 0.0
+    bad = fam[0][: 64].copy(); bad[::2, 3] = np.nan; bad[1::4, 0] = np.inf; bad[3::4, 4] = -np.inf
+    fam += [r, z, bad]
+    return np.vstack(fam)
+
+
+@pytest.mark.parametrize("prec,scene_id", [(32, 3), (32, 1), (64, 3), (64, 1), (32, 2)])
+def test_hit_world_ray_by_ray_grid_vs_exact(rt, prec, scene_id):
+    """hit_world alone (rtiow_debug_hit_world) on ~1.3 million adversarial rays: the grid walk returns the same
+    (root bits, sphere index) as the 12-operation loop over every sphere, ray by ray."""
+    from tests.test_grid_plan import _plan
+    sc = rt.build_scene(scene_id, prec)
+    keep = sc["valid"] != 0
+    cr = sc["center_radius"][keep].astype(np.float64)
+    pl = _plan(rt, cr)
+    assert pl["usable"]
+    rays = _adversarial_rays(np.random.default_rng(100 * scene_id + prec), cr, pl, 200000)
+    dt = np.float32 if prec == 32 else np.float64
+    with np.errstate(over="ignore", invalid="ignore"):
+        rays = rays.astype(dt)
+    out = {}
+    for source in (rt.SCENE_GRID, rt.SCENE_LDS_EXACT, rt.SCENE_LDS):
+        with rt.Renderer(0, prec) as r:
+            r.set_camera(rt.camera(prec, 64, 64, 1, 1)); r.set_scene(sc); r.set_scene_source(source)
+            out[source] = r.debug_hit_world(rays)
+            if source == rt.SCENE_GRID:
+                assert r.stats()["scene_source"] == rt.SCENE_GRID
+    t_ref, i_ref = out[rt.SCENE_LDS_EXACT]
+    hit_frac = float((i_ref >= 0).mean())
+    assert 0.2 < hit_frac < 0.95, hit_frac                                  # the families do hit things, and do miss
+    for source in (rt.SCENE_GRID, rt.SCENE_LDS):
+        t, i = out[source]
+        bad = np.nonzero((i != i_ref) | (t.view(np.uint8).reshape(len(t), -1) != t_ref.view(np.uint8).reshape(len(t), -1)).any(axis=1))[0]
+        assert len(bad) == 0, (source, len(bad), rays[bad[:5]], t[bad[:5]], t_ref[bad[:5]], i[bad[:5]], i_ref[bad[:5]])
+
+
 def test_screen_equals_exact_on_the_488_sphere_scene(rt):
     """Scene 1 at 1280x720x20: the screened loop (default) vs the exact loop, bit for bit."""
     a = _render(rt, 32, 1, 1280, 720, 20, 50, threads=0, source=rt.SCENE_LDS)
