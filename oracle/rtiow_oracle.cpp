@@ -831,6 +831,29 @@ int oracle_sky(int policy, const double* dir3, double* out3) {
     return -1;
 }
 
+// hit_world (hittable.h:80-98, CUDA policy: explicit fma, tmin 0.001, tmax infinity) alone on n caller-supplied
+// rays {ox,oy,oz,dx,dy,dz}: nearest root (+inf: none) and sphere index (-1) per ray.  Twin of the library's
+// rtiow_debug_hit_world, for ray-by-ray comparison (tests/test_gpu_parity.py).
+int oracle_hit_world(int precision, int n_spheres, const void* center_radius, int n_rays, const void* rays, void* t_out, int* index_out) {
+    auto run = [&](auto tag) {
+        using T = decltype(tag);
+        const T* cr = (const T*)center_radius; const T* r = (const T*)rays; T* t = (T*)t_out;
+        World<T> w;
+        for (int i = 0; i < n_spheres; ++i) { w.center.push_back({cr[4 * i], cr[4 * i + 1], cr[4 * i + 2]}); w.radius.push_back(cr[4 * i + 3]); }
+        w.n = n_spheres;
+        for (int k = 0; k < n_rays; ++k) {
+            Hit<T> rec;
+            const bool any = hit_world<true, T>(w, {r[6 * k], r[6 * k + 1], r[6 * k + 2]}, {r[6 * k + 3], r[6 * k + 4], r[6 * k + 5]}, (T)0.001, std::numeric_limits<T>::infinity(), rec);
+            t[k] = any ? rec.t : std::numeric_limits<T>::infinity();
+            index_out[k] = any ? rec.idx : -1;
+        }
+    };
+    if (precision == 32) run(float());
+    else if (precision == 64) run(double());
+    else return -1;
+    return 0;
+}
+
 // Single-primitive probes used by the analytic known-answer tests (tests/test_oracle_kat.py).
 int oracle_hit_sphere_f64(const double* center, double radius, const double* O, const double* D, double tmin, double tmax,
                           double* t, double* p3, double* n3, int* front) {

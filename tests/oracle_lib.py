@@ -146,6 +146,15 @@ class Oracle:
             return out, [int(x) for x in stats], seg
         return out, [int(x) for x in stats]
 
+    def hit_world(self, prec, center_radius, rays):
+        """hit_world alone on rays [n, 6]: (t [n] (+inf: none), sphere index [n] (-1: none))."""
+        dt = _dt(prec)
+        cr = np.ascontiguousarray(center_radius, dt); rays = np.ascontiguousarray(rays, dt)
+        t = np.zeros(len(rays), dt); idx = np.zeros(len(rays), np.int32)
+        self.L.oracle_hit_world.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        assert self.L.oracle_hit_world(prec, len(cr), cr.ctypes.data, len(rays), rays.ctypes.data, t.ctypes.data, idx.ctypes.data) == 0
+        return t, idx
+
     def render_serial(self, scene_id, W, H, S, depth, loop_form=RECURSIVE, sky_mode=SKY_CURRENT):
         """Serial-policy render (P3 text).  The defaults are the reference's serial program."""
         cap = W * H * 12 + 64

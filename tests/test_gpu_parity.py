@@ -548,7 +548,7 @@ def _adversarial_rays(rng, cr, plan, n_each):
 
 
 @pytest.mark.parametrize("prec,scene_id", [(32, 3), (32, 1), (64, 3), (64, 1), (32, 2)])
-def test_hit_world_ray_by_ray_grid_vs_exact(rt, prec, scene_id):
+def test_hit_world_ray_by_ray_grid_vs_exact(rt, oracle, prec, scene_id):
     """hit_world alone (rtiow_debug_hit_world) on ~1.3 million adversarial rays: the grid walk returns the same
     (root bits, sphere index) as the 12-operation loop over every sphere, ray by ray."""
     from tests.test_grid_plan import _plan
@@ -575,6 +575,11 @@ def test_hit_world_ray_by_ray_grid_vs_exact(rt, prec, scene_id):
         t, i = out[source]
         bad = np.nonzero((i != i_ref) | (t.view(np.uint8).reshape(len(t), -1) != t_ref.view(np.uint8).reshape(len(t), -1)).any(axis=1))[0]
         assert len(bad) == 0, (source, len(bad), rays[bad[:5]], t[bad[:5]], t_ref[bad[:5]], i[bad[:5]], i_ref[bad[:5]])
+    # and the oracle's in-order loop (hittable.h:80-98 restated on the CPU), ray by ray, on a slice of every family
+    pick = np.arange(0, len(rays), 7)
+    t_o, i_o = oracle.hit_world(prec, cr.astype(dt), rays[pick])
+    bad = np.nonzero((i_o != i_ref[pick]) | (t_o.view(np.uint8).reshape(len(pick), -1) != t_ref[pick].view(np.uint8).reshape(len(pick), -1)).any(axis=1))[0]
+    assert len(bad) == 0, (len(bad), rays[pick][bad[:5]], t_o[bad[:5]], t_ref[pick][bad[:5]], i_o[bad[:5]], i_ref[pick][bad[:5]])
 
 
 def test_screen_equals_exact_on_the_488_sphere_scene(rt):
