@@ -335,9 +335,9 @@ def main():
                      "frac_of_peak": round(flops_step / (kms * 1e-3) / 1e12 / peak, 4)},
         }
         line["scaling_detail"] = {
-            "floor_ms": round(floor_ms, 4), "floor_is": "prepass_ms + longest per-pixel chain of the main launch x lone-ray trip latency, max over ranks; a LOWER bound: the probe "
-                                                                "pixel's trips are ground/sky hits, the longest chains bounce inside glass, where a trip (two IEEE square roots and divisions "
-                                                                "in the dielectric scatter) takes about twice as long (DESIGN.md section 5)",
+            "floor_ms": round(floor_ms, 4), "floor_is": "prepass_ms + longest per-pixel chain of the main launch x the trip latency of a lone ray on an idle GPU (1-pixel probe), max over ranks: "
+                                                                "what a rank reaches if its longest chain runs undisturbed from the first trip; shards run it at about twice that "
+                                                                "latency because the SIMDs stay loaded with sparse waves (DESIGN.md section 5)",
             "longest_chain_segments": chain_max, "lone_ray_trip_us": round(trip_us, 4) if trip_us else None,
             "lone_ray_probe": "1x1 frame, 400 spp, %d segments" % trip_segments,
             "kernel_ms_per_rank": kernel_ms_per_rank, "gather_ms_per_rank": gather_ms_per_rank,
