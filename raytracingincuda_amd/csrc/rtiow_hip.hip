@@ -1413,6 +1413,31 @@ __global__ void __launch_bounds__(256) hit_probe_kernel(const RenderParams<T> p,
 constexpr int COST_BINS = 1024;
 __device__ __forceinline__ int cost_bin(unsigned c) { return c < (unsigned)COST_BINS ? (int)c : COST_BINS - 1; }
 
+// What the sort ranks a pixel by: the prepass cost averaged over its (2 hw + 1)^2 neighbourhood (inside its
+// own row strip), in quarter segments.  A pixel's own 3 samples predict the cost of its remaining 97 poorly
+// (correlation 0.51 on the oracle's segment maps: half a percent of the heaviest pixels were handed out after
+// more than half of the frame's work); heavy pixels cluster -- the rims of the glass spheres, the crevices
+// between spheres -- and the 75 samples of a 5 x 5 neighbourhood predict it well (0.91; the same pixels then
+// start within the first 16 %).  Measured: headline 14.6 -> 13.5 ms, 1280x720 10.0 -> 8.6, half-frame shard
+// 10.6 -> 8.5, scene 1 26.0 -> 23.8 (hw = 6).  hw = half-width of the window.
+__global__ void __launch_bounds__(256) cost_smooth_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ out, int W, int rows, int strip_rows, int hw) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= W * rows) return;
+    const int jl = k / W, i = k - jl * W;
+    const int s0 = (jl / strip_rows) * strip_rows;                                   // rows of other strips are not neighbours in the image
+    const int j0 = jl - hw > s0 ? jl - hw : s0;
+    int j1 = jl + hw < s0 + strip_rows - 1 ? jl + hw : s0 + strip_rows - 1;
+    if (j1 > rows - 1) j1 = rows - 1;
+    const int i0 = i - hw > 0 ? i - hw : 0, i1 = i + hw < W - 1 ? i + hw : W - 1;
+    unsigned sum = 0;
+    for (int j = j0; j <= j1; ++j)
+        for (int x = i0; x <= i1; ++x) sum += cost[j * W + x];
+    // mean over the window actually covered, in quarter segments: the bins keep their resolution at the image
+    // border and in two-row strips
+    const unsigned cells = (unsigned)((j1 - j0 + 1) * (i1 - i0 + 1));
+    out[k] = (4u * sum + cells / 2) / cells;
+}
+
 __global__ void __launch_bounds__(256) cost_hist_kernel(const uint32_t* __restrict__ cost, int npix, unsigned* __restrict__ hist) {
     __shared__ unsigned local[COST_BINS];
     for (int b = threadIdx.x; b < COST_BINS; b += blockDim.x) local[b] = 0;
@@ -1581,6 +1606,7 @@ struct rtiow_handle_s {
     int schedule = RTIOW_SCHED_SORTED;
     unsigned char* mid = nullptr; size_t mid_bytes = 0;          // SCHED_SORTED: MidState records parked between the launches
     uint32_t* cost = nullptr; size_t cost_bytes = 0;
+    uint32_t* cost_rank = nullptr; size_t cost_rank_bytes = 0;    // the smoothed cost the sort ranks by
     int* order = nullptr; size_t order_bytes = 0;
     unsigned* sort_scratch = nullptr; size_t sort_scratch_bytes = 0;
     int waves_per_simd = 0;
@@ -2085,6 +2111,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             int rc;
             if ((rc = ensure_buffer(h, &h->mid, &h->mid_bytes, (size_t)npix * sizeof(MidState<T>)))) return rc;
             if ((rc = ensure_buffer(h, &h->cost, &h->cost_bytes, (size_t)npix * sizeof(uint32_t)))) return rc;
+            if ((rc = ensure_buffer(h, &h->cost_rank, &h->cost_rank_bytes, (size_t)npix * sizeof(uint32_t)))) return rc;
             if ((rc = ensure_buffer(h, &h->order, &h->order_bytes, (size_t)total_pools * POOL * sizeof(int)))) return rc;
             if ((rc = ensure_buffer(h, &h->sort_scratch, &h->sort_scratch_bytes, (size_t)3 * COST_BINS * sizeof(unsigned)))) return rc;
             if (prepare_only) return 0;                  // every table and buffer of this configuration now exists
@@ -2106,7 +2133,16 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             HIP_TRY(h, hipMemsetAsync(hist, 0, COST_BINS * sizeof(unsigned), h->stream));
             HIP_TRY(h, hipMemsetAsync(h->order, 0xff, (size_t)total_pools * POOL * sizeof(int), h->stream));
             const int sort_blocks = (npix + 255) / 256;
-            hipLaunchKernelGGL(cost_hist_kernel, dim3(sort_blocks < 1024 ? sort_blocks : 1024), dim3(256), 0, h->stream, h->cost, npix, hist);
+            const uint32_t* rank_by = h->cost;
+            int smooth_hw = 6;                          // 13 x 13 window: profiles/r02_cost_smoothing_sweep.jsonl
+#ifdef RTIOW_TUNING
+            if (const char* e = std::getenv("RTIOW_TUNE_SMOOTH")) smooth_hw = std::atoi(e);
+#endif
+            if (smooth_hw > 0) {
+                hipLaunchKernelGGL(cost_smooth_kernel, dim3(sort_blocks), dim3(256), 0, h->stream, h->cost, h->cost_rank, p.cold.W, h->local_rows, h->strip_rows, smooth_hw);
+                rank_by = h->cost_rank;
+            }
+            hipLaunchKernelGGL(cost_hist_kernel, dim3(sort_blocks < 1024 ? sort_blocks : 1024), dim3(256), 0, h->stream, rank_by, npix, hist);
             hipLaunchKernelGGL(cost_scan_kernel, dim3(1), dim3(COST_BINS), 0, h->stream, hist, start, fill);
             const int resident_waves = (int)blocks * waves_per_block;
             const int age_classes = (int)((blocks + h->num_cus - 1) / h->num_cus);
@@ -2121,13 +2157,15 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             // frames are fastest with 1.
             const double pools_per_wave = (double)total_pools / (double)resident_waves;
             // With the grid walk (a lane's cost follows ITS ray) coherence pays more: whole pools of 64 neighbouring
-            // ranks on the full frame, 15.3 -> 14.7 ms; the smaller frames keep their mix (profiles/r02_tune_sweep.jsonl).
-            int deal_group = pools_per_wave >= 5.0 ? 64 : (pools_per_wave >= 2.5 ? 8 : 1);
+            // ranks, 15.3 -> 14.7 ms on the full frame (profiles/r02_tune_sweep.jsonl) and, once the ranks come from
+            // the smoothed cost, on every frame with at least 2.5 pools per wave (1280x720: 9.3 ms with groups of 1,
+            // 11.4 with 8, 8.7 with 64; profiles/r02_cost_smoothing_sweep.jsonl); smaller shards keep single ranks.
+            int deal_group = pools_per_wave >= 2.5 ? 64 : 1;
 #ifdef RTIOW_TUNING
             if (const char* e = std::getenv("RTIOW_TUNE_DEAL")) deal_group = std::atoi(e);
 #endif
             const int scatter_blocks = ((p.cold.W + 63) / 64) * ((h->local_rows + 63) / 64);   // one per 64 x 64 super-tile
-            hipLaunchKernelGGL(cost_scatter_kernel, dim3(scatter_blocks), dim3(1024), 0, h->stream, h->cost, p.cold.W, h->local_rows, start, fill, h->order,
+            hipLaunchKernelGGL(cost_scatter_kernel, dim3(scatter_blocks), dim3(1024), 0, h->stream, rank_by, p.cold.W, h->local_rows, start, fill, h->order,
                                pools_per_block, total_pools, deal_group);
             HIP_TRY(h, hipGetLastError());
             // ---- main launch: samples [SA, S) in that order
@@ -2244,7 +2282,7 @@ int rtiow_destroy(rtiow_handle h) {
     if (!h) return RTIOW_E_BADARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->geom_a, h->shade_tbl, h->geom_s, h->grid_blob, h->rng, h->jump, h->work_counter, h->mid,
+    void* bufs[] = {h->geom_a, h->shade_tbl, h->geom_s, h->grid_blob, h->cost_rank, h->rng, h->jump, h->work_counter, h->mid,
                     h->cost, h->order, h->sort_scratch, h->fb_external ? nullptr : h->fb};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);

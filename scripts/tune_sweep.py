@@ -5,7 +5,7 @@ import numpy as np
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = os.path.join(root, "raytracingincuda_amd", "lib", "ab", "tuning.so")
 extra = sys.argv[1:]
-cases = [("default", {})] + [("lane_cap=%d" % c, {"RTIOW_TUNE_LANE_CAP": str(c)}) for c in (8, 16, 32, 64)] + [("lane_cap=%d,wps=%d" % (c, w), {"RTIOW_TUNE_LANE_CAP": str(c), "RTIOW_TUNE_WPS": str(w)}) for c in (32, 64) for w in (1, 2)]
+cases = [("smooth=%d,SA=%d" % (sm, sa), {"RTIOW_TUNE_SMOOTH": str(sm), "RTIOW_TUNE_SA": str(sa)}) for sm in (4, 6, 8) for sa in (1, 2, 3)] + [("smooth=0,SA=3", {"RTIOW_TUNE_SMOOTH": "0"})]
 times = {c[0]: [] for c in cases}
 for rd in range(2):
     for name, env in cases:
