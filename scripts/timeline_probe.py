@@ -18,4 +18,4 @@ def main(shard=None, lr=0, wps=0, threads=0, sched=2):
                       "us_per_normal_iter": q((np.nan_to_num(exh, nan=0) - start)[tl[:, 3] > 0] / tl[:, 3][tl[:, 3] > 0]),
                       "us_per_coop_iter": q(((end - exh)[tl[:, 4] > 0]) / tl[:, 4][tl[:, 4] > 0])}), flush=True)
     r.close()
-main(); main(shard=(1, 2, 8)); main(shard=(1, 4, 2)); main(shard=(3, 8, 2))
+main(); main(shard=(1, 2, 8))
