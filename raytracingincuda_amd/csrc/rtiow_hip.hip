@@ -993,14 +993,22 @@ __device__ __forceinline__ void coop_solo(const RenderParams<double>&, const dou
 // N/g, which is what bounds the kernel once only the long glass paths are left.
 template <class T> struct CoopSlot { T ox, oy, oz, a, dx, dy, dz, pad; };
 
+// log2 of the lanes each of n rays gets when a wave of `lanes` lanes splits their sphere loops: floor(log2(lanes)) -
+// ceil(log2(n)) -- exact for the 64-lane waves of the dynamic schedules, never too large otherwise (two count-
+// leading-zeros instead of a loop: this runs every trip of the drain, where a lone ray's trip is all latency).
+__device__ __forceinline__ int lanes_per_ray_log2(int n, int lanes) {
+    const int up = n > 1 ? 32 - __builtin_clz((unsigned)(n - 1)) : 0;
+    const int lg = (31 - __builtin_clz((unsigned)lanes)) - up;
+    return lg > 0 ? lg : 0;
+}
+
 template <class T, int SRC>
 __device__ __forceinline__ void hit_world_coop(const RenderParams<T>& p, const T* lds_geom, CoopSlot<T>* slots,
                                                bool alive, unsigned long long alive_mask, int n_alive, int wave_lanes,
                                                V3<T> O, V3<T> D, T a, T& closest, int& hit) {
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(alive_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)alive_mask, 0u));
-    int lg = 0;                                    // g = 2^lg lanes per ray, n_alive * g <= lanes of this wave
-    while ((n_alive << (lg + 1)) <= wave_lanes) ++lg;
+    const int lg = lanes_per_ray_log2(n_alive, wave_lanes);   // g = 2^lg lanes per ray, n_alive * g <= lanes of this wave
     const int g = 1 << lg;
     if (alive) slots[rank] = {O.x, O.y, O.z, a, D.x, D.y, D.z, (T)0};
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1296,8 +1304,7 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
             // With a grid, sharing the brute-force loop only pays while a ray's share of it is short: g lanes per
             // ray leave it n_trips / g trips of ~38 instructions, the grid path costs ~300 whatever the lane count.
             const int n_need = __builtin_popcountll(hit_mask);
-            int lg = 0;
-            while ((n_need << (lg + 1)) <= wave_lanes) ++lg;
+            const int lg = lanes_per_ray_log2(n_need, wave_lanes);
             share_loops = ((p.n_padded >> 2) + (1 << lg) - 1) >> lg <= RTIOW_COOP_MAX_TRIPS;
         }
         if (share_loops) {
