@@ -970,7 +970,20 @@ __device__ __forceinline__ void hit_world_solo(const RenderParams<float>& p, con
     float best = __builtin_huge_valf();
     int best_idx = -1;
     for (int s = lane * 4; s < p.n_padded; s += 256) sphere_trip<float>(gm, s, r, best, best_idx);
-    const unsigned long long k = wave_min_key(__float_as_uint(best), (unsigned)best_idx);
+    // Few lanes hold a hit at all (the ray meets a handful of spheres): walk those lanes with readlanes -- a short
+    // scalar loop -- instead of the 64-lane DPP minimum, which is ~60 dependent instructions of pure latency here.
+    const unsigned long long holders = __builtin_amdgcn_ballot_w64(best_idx >= 0);
+    unsigned long long k = ~0ull;
+    if (__builtin_popcountll(holders) <= 6) {
+        unsigned long long m = holders;
+        while (m != 0) {
+            const int l = (int)__builtin_ctzll(m);
+            m &= m - 1;
+            const unsigned long long kl = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(best), l) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane(best_idx, l);
+            k = kl < k ? kl : k;
+        }
+    } else k = wave_min_key(__float_as_uint(best), (unsigned)best_idx);
     if (is_owner) { closest = __uint_as_float((unsigned)(k >> 32)); hit = (int)(unsigned)k; }
 }
 
