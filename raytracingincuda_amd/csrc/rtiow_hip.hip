@@ -973,7 +973,7 @@ __device__ __forceinline__ void hit_world_solo(const RenderParams<float>& p, con
     // Few lanes hold a hit at all (the ray meets a handful of spheres): walk those lanes with readlanes -- a short
     // scalar loop -- instead of the 64-lane DPP minimum, which is ~60 dependent instructions of pure latency here.
     const unsigned long long holders = __builtin_amdgcn_ballot_w64(best_idx >= 0);
-    unsigned long long k = ~0ull;
+    unsigned long long k = 0x7f800000ffffffffull;   // {+inf, -1}: no hit
     if (__builtin_popcountll(holders) <= 6) {
         unsigned long long m = holders;
         while (m != 0) {
@@ -1035,6 +1035,26 @@ __device__ __forceinline__ void hit_world_coop(const RenderParams<T>& p, const T
         const LoopRay<T> r = make_loop_ray(cs.ox, cs.oy, cs.oz, cs.dx, cs.dy, cs.dz, cs.a);
         const T* gm = (SRC == RTIOW_SCENE_LDS) ? lds_geom : p.geom_a;
         for (int s = sub * 4; s < p.n_padded; s += g * 4) sphere_trip<T>(gm, s, r, best, best_idx);
+    }
+    if (sizeof(T) == 4 && n_alive <= 4) {
+        // Few rays, wide groups: the xor-shuffle reduction below is log2(g) dependent LDS round trips (five for two
+        // rays).  A ray meets a handful of spheres, so few lanes of its group hold a hit: walk those lanes with
+        // readlanes, ray by ray, and hand the result to the ray's owner -- all scalar, no LDS.
+        const unsigned long long holders = __builtin_amdgcn_ballot_w64(best_idx >= 0);
+        const unsigned long long group_lanes = g >= 64 ? ~0ull : ((1ull << g) - 1);
+        for (int j = 0; j < n_alive; ++j) {
+            unsigned long long m = holders & (group_lanes << (j << lg));
+            unsigned long long k = 0x7f800000ffffffffull;   // {+inf, -1}: no hit
+            while (m != 0) {
+                const int l = (int)__builtin_ctzll(m);
+                m &= m - 1;
+                const unsigned long long kl = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)__float_as_uint((float)best), l) << 32) |
+                                              (unsigned)__builtin_amdgcn_readlane(best_idx, l);
+                k = kl < k ? kl : k;
+            }
+            if (alive && rank == j) { closest = (T)__uint_as_float((unsigned)(k >> 32)); hit = (int)(unsigned)k; }
+        }
+        return;
     }
     // lexicographic (t, index) minimum over the g lanes of the group
     for (int off = 1; off < g; off <<= 1) {
