@@ -1006,6 +1006,14 @@ __device__ __forceinline__ void coop_solo(const RenderParams<double>&, const dou
 // N/g, which is what bounds the kernel once only the long glass paths are left.
 template <class T> struct CoopSlot { T ox, oy, oz, a, dx, dy, dz, pad; };
 
+// the value lane l holds, as a wave-uniform scalar
+__device__ __forceinline__ float lane_value(float v, int l) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); }
+__device__ __forceinline__ double lane_value(double v, int l) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // log2 of the lanes each of n rays gets when a wave of `lanes` lanes splits their sphere loops: floor(log2(lanes)) -
 // ceil(log2(n)) -- exact for the 64-lane waves of the dynamic schedules, never too large otherwise (two count-
 // leading-zeros instead of a loop: this runs every trip of the drain, where a lone ray's trip is all latency).
@@ -1036,23 +1044,27 @@ __device__ __forceinline__ void hit_world_coop(const RenderParams<T>& p, const T
         const T* gm = (SRC == RTIOW_SCENE_LDS) ? lds_geom : p.geom_a;
         for (int s = sub * 4; s < p.n_padded; s += g * 4) sphere_trip<T>(gm, s, r, best, best_idx);
     }
-    if (sizeof(T) == 4 && n_alive <= 4) {
+    if (n_alive <= 4) {
         // Few rays, wide groups: the xor-shuffle reduction below is log2(g) dependent LDS round trips (five for two
-        // rays).  A ray meets a handful of spheres, so few lanes of its group hold a hit: walk those lanes with
-        // readlanes, ray by ray, and hand the result to the ray's owner -- all scalar, no LDS.
+        // rays; fp64 has no single-ray path, so six for one).  A ray meets a handful of spheres, so few lanes of its
+        // group hold a hit: walk those lanes with readlanes, ray by ray, and hand the result to the ray's owner --
+        // all scalar, no LDS.
         const unsigned long long holders = __builtin_amdgcn_ballot_w64(best_idx >= 0);
         const unsigned long long group_lanes = g >= 64 ? ~0ull : ((1ull << g) - 1);
         for (int j = 0; j < n_alive; ++j) {
             unsigned long long m = holders & (group_lanes << (j << lg));
-            unsigned long long k = 0x7f800000ffffffffull;   // {+inf, -1}: no hit
+            T bt = __builtin_huge_val();
+            int bi = -1;
             while (m != 0) {
                 const int l = (int)__builtin_ctzll(m);
                 m &= m - 1;
-                const unsigned long long kl = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)__float_as_uint((float)best), l) << 32) |
-                                              (unsigned)__builtin_amdgcn_readlane(best_idx, l);
-                k = kl < k ? kl : k;
+                const T tl = lane_value(best, l);
+                const int il = __builtin_amdgcn_readlane(best_idx, l);
+                const bool take = (tl < bt) || (tl == bt && (unsigned)il < (unsigned)bi);
+                bt = take ? tl : bt;
+                bi = take ? il : bi;
             }
-            if (alive && rank == j) { closest = (T)__uint_as_float((unsigned)(k >> 32)); hit = (int)(unsigned)k; }
+            if (alive && rank == j) { closest = bt; hit = bi; }
         }
         return;
     }
