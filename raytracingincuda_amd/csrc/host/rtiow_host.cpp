@@ -160,25 +160,53 @@ template <class T> inline int to_level(T c) {                   // main.cu:367,3
     return (int)(256 * cl);
 }
 
+// Levels 0..255 as text, four bytes each ("255 " style: digits then blank padding is NOT used -- the entry holds
+// the digits and its length), so the writer copies a table entry per channel instead of dividing.
+struct LevelText { char s[4]; unsigned char n; };
+const LevelText* level_table() {
+    static LevelText tab[256];
+    static bool ready = false;
+    if (!ready) {
+        for (int v = 0; v < 256; ++v) {
+            char buf[8];
+            const int n = std::snprintf(buf, sizeof buf, "%d", v);
+            std::memcpy(tab[v].s, buf, (size_t)n);
+            tab[v].n = (unsigned char)n;
+        }
+        ready = true;
+    }
+    return tab;
+}
+
 template <class T>
 void format_ppm_t(int width, int height, const T* rgb, std::string& out) {
     char head[64];
-    std::snprintf(head, sizeof head, "P3\n%d %d\n255\n", width, height);
-    out.assign(head);
-    out.reserve(out.size() + (size_t)width * height * 12);
-    char digits[16];
+    const int hn = std::snprintf(head, sizeof head, "P3\n%d %d\n255\n", width, height);
     const size_t npix = (size_t)width * height;
+    out.resize((size_t)hn + npix * 3 * 12);                         // "-2147483648 " is the longest channel
+    char* w = &out[0];
+    std::memcpy(w, head, (size_t)hn);
+    w += hn;
+    const LevelText* tab = level_table();
     for (size_t p = 0; p < npix; ++p) {
         for (int k = 0; k < 3; ++k) {
             const int level = to_level<T>(rgb[3 * p + k]);
-            unsigned v = (unsigned)level;
-            int n = 0;
-            if (level < 0) { out.push_back('-'); v = 0u - v; } // only the NaN level is negative; unsigned negation is defined for INT_MIN
-            do { digits[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-            while (n) out.push_back(digits[--n]);
-            out.push_back(k == 2 ? '\n' : ' ');
+            if (level >= 0) {                                       // 0..255 by construction (clamp to 0.999)
+                const LevelText& t = tab[level & 255];
+                std::memcpy(w, t.s, 4);                             // fixed-size copy, then advance by the real length
+                w += t.n;
+            } else {                                                // only the NaN level is negative; unsigned negation is defined for INT_MIN
+                unsigned v = 0u - (unsigned)level;
+                char digits[16];
+                int n = 0;
+                *w++ = '-';
+                do { digits[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+                while (n) *w++ = digits[--n];
+            }
+            *w++ = k == 2 ? '\n' : ' ';
         }
     }
+    out.resize((size_t)(w - &out[0]));
 }
 
 }  // namespace
