@@ -26,7 +26,7 @@ HIP_FLAGS = [
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
     "-fno-fast-math", "-I" + INC,
 ]
-HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-I" + INC]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-I" + INC]
 
 
 def _hipcc():

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -178,17 +179,12 @@ const LevelText* level_table() {
     return tab;
 }
 
+// Text of the pixels [p0, p1): "r g b\n" per pixel (main.cu:372-377).  Returns the end of what was written;
+// the buffer must hold 36 bytes per pixel ("-2147483648 " is the longest channel).
 template <class T>
-void format_ppm_t(int width, int height, const T* rgb, std::string& out) {
-    char head[64];
-    const int hn = std::snprintf(head, sizeof head, "P3\n%d %d\n255\n", width, height);
-    const size_t npix = (size_t)width * height;
-    out.resize((size_t)hn + npix * 3 * 12);                         // "-2147483648 " is the longest channel
-    char* w = &out[0];
-    std::memcpy(w, head, (size_t)hn);
-    w += hn;
+char* format_pixels(const T* rgb, size_t p0, size_t p1, char* w) {
     const LevelText* tab = level_table();
-    for (size_t p = 0; p < npix; ++p) {
+    for (size_t p = p0; p < p1; ++p) {
         for (int k = 0; k < 3; ++k) {
             const int level = to_level<T>(rgb[3 * p + k]);
             if (level >= 0) {                                       // 0..255 by construction (clamp to 0.999)
@@ -206,7 +202,45 @@ void format_ppm_t(int width, int height, const T* rgb, std::string& out) {
             *w++ = k == 2 ? '\n' : ' ';
         }
     }
-    out.resize((size_t)(w - &out[0]));
+    return w;
+}
+
+// The whole file as `parts` (header first), formatted by up to 8 threads over contiguous pixel ranges: the text
+// writer is the largest part of the end-to-end time after the render (12 ms of 33 at 1280x768).
+template <class T>
+void format_ppm_parts(int width, int height, const T* rgb, std::vector<std::string>& parts) {
+    char head[64];
+    const int hn = std::snprintf(head, sizeof head, "P3\n%d %d\n255\n", width, height);
+    const size_t npix = (size_t)width * height;
+    (void)level_table();                                            // built before the threads start
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 8) nt = 8;
+    if (nt < 1 || npix < 65536) nt = 1;
+    parts.assign(nt + 1, std::string());
+    parts[0].assign(head, (size_t)hn);
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nt; ++k) {
+        const size_t p0 = npix * k / nt, p1 = npix * (k + 1) / nt;
+        auto work = [&parts, rgb, p0, p1, k]() {
+            std::string& out = parts[k + 1];
+            out.resize((p1 - p0) * 36);
+            char* e = format_pixels<T>(rgb, p0, p1, &out[0]);
+            out.resize((size_t)(e - &out[0]));
+        };
+        if (nt == 1) work(); else th.emplace_back(work);
+    }
+    for (std::thread& t : th) t.join();
+}
+
+template <class T>
+void format_ppm_t(int width, int height, const T* rgb, std::string& out) {
+    std::vector<std::string> parts;
+    format_ppm_parts<T>(width, height, rgb, parts);
+    size_t total = 0;
+    for (const std::string& p : parts) total += p.size();
+    out.clear();
+    out.reserve(total);
+    for (const std::string& p : parts) out += p;
 }
 
 }  // namespace
@@ -255,13 +289,14 @@ int rtiow_host_format_ppm(int precision, int width, int height, const void* rgb,
 
 int rtiow_host_write_ppm(const char* path, int precision, int width, int height, const void* rgb) {
     if (!path || !rgb || width <= 0 || height <= 0) return RTIOW_E_BADARG;
-    std::string s;
-    if (precision == 32) format_ppm_t<float>(width, height, (const float*)rgb, s);
-    else if (precision == 64) format_ppm_t<double>(width, height, (const double*)rgb, s);
+    std::vector<std::string> parts;
+    if (precision == 32) format_ppm_parts<float>(width, height, (const float*)rgb, parts);
+    else if (precision == 64) format_ppm_parts<double>(width, height, (const double*)rgb, parts);
     else return RTIOW_E_BADARG;
     std::FILE* f = std::fopen(path, "wb");
     if (!f) return RTIOW_E_STATE;
-    const bool ok = std::fwrite(s.data(), 1, s.size(), f) == s.size();
+    bool ok = true;
+    for (const std::string& p : parts) ok = ok && std::fwrite(p.data(), 1, p.size(), f) == p.size();
     return (std::fclose(f) == 0 && ok) ? 0 : RTIOW_E_STATE;
 }
 
