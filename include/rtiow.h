@@ -113,6 +113,9 @@ typedef struct {
     int32_t  grid_registered;    /* spheres binned into cells (each in up to 2 x 2 of them)       */
     int32_t  grid_direct;        /* spheres every ray tests exactly (too big for a cell / overflow) */
     double   grid_cell;          /* cell width                                                    */
+    /* RTIOW_SCHED_SORTED on a partly filled GPU (small frame, shard): waves that held only the top-ranked
+     * pixels, and how many each (0: the plain kernel ran) */
+    int32_t  solo_waves, solo_lanes;
 } rtiow_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------

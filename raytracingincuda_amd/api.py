@@ -67,7 +67,8 @@ class Stats(ctypes.Structure):
                 ("segments_prepass", ctypes.c_uint64), ("segments_main", ctypes.c_uint64),
                 ("max_chain_prepass", ctypes.c_uint64), ("max_chain_main", ctypes.c_uint64),
                 ("grid_nx", ctypes.c_int32), ("grid_nz", ctypes.c_int32), ("grid_registered", ctypes.c_int32),
-                ("grid_direct", ctypes.c_int32), ("grid_cell", ctypes.c_double)]
+                ("grid_direct", ctypes.c_int32), ("grid_cell", ctypes.c_double),
+                ("solo_waves", ctypes.c_int32), ("solo_lanes", ctypes.c_int32)]
 
 
 class GroupStats(ctypes.Structure):

@@ -308,10 +308,10 @@ int main(int argc, char** argv) {
         const double rays = (double)opt.width * opt.height * opt.samples;
         std::fprintf(stderr,
                      "{\"mrays_per_s\": %.3f, \"render_ms\": %.6f, \"rng_init_ms\": %.6f, \"spheres\": %d, \"block\": [%d, %d], "
-                     "\"vgprs\": %d, \"lds_bytes\": %d, \"scene_source\": \"%s\", "
+                     "\"vgprs\": %d, \"lds_bytes\": %d, \"scene_source\": \"%s\", \"solo_waves\": %d, "
                      "\"wall_ms\": {\"setup\": %.3f, \"rng_init\": %.3f, \"render\": %.3f, \"readback\": %.3f, \"ppm_write\": %.3f, \"end_to_end\": %.3f}}\n",
                      render_ms > 0 ? rays / render_ms / 1e3 : 0.0, (double)render_ms, st.rng_init_ms, st.num_spheres,
-                     st.block_x, st.block_y, st.vgprs, st.lds_bytes, st.scene_source == RTIOW_SCENE_GRID ? "grid" : (st.scene_source == RTIOW_SCENE_SCALAR ? "scalar" : "lds"),
+                     st.block_x, st.block_y, st.vgprs, st.lds_bytes, st.scene_source == RTIOW_SCENE_GRID ? "grid" : (st.scene_source == RTIOW_SCENE_SCALAR ? "scalar" : "lds"), st.solo_waves,
                      t_setup, t_rng, t_render, t_read, t_write, e2e_ms);
     }
     return 0;

@@ -190,6 +190,9 @@ template <class T> struct ColdParams {
     const int* __restrict__ order;    // slot -> local pixel (or -1), nullptr: 8x8 tiles bottom-up
     int total_slots;
     int first_pools;                  // 1: wave w starts with pool w (the work counter then starts at the wave count)
+    // Solo waves: the first solo_waves*solo_lanes slots of the order (the heaviest pixels) go solo_lanes each to
+    // wave 0 of the first solo_waves workgroups, which take nothing else until those pixels are done.
+    int solo_waves, solo_lanes;
     unsigned long long* timeline;     // COUNT variant, optional: per wave {t_start, t_exhausted, t_end, iters_normal, iters_coop, pixels, 0, 0}
 };
 
@@ -1230,7 +1233,7 @@ constexpr int POOL = 64;
 #define RTIOW_COOP_MAX_TRIPS 6
 #endif
 
-template <class T, int SRC, bool COUNT>
+template <class T, int SRC, bool COUNT, bool SOLO = false>
 __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
     const T* lds_geom = stage_scene<T, SRC>(p);
     // per-wave scratch for hit_world_coop, behind the staged tables
@@ -1253,18 +1256,38 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
     // dispatched in blockIdx order and the SIMD arbiter favours older waves, so this puts the
     // heaviest block of the cost-sorted order on the waves that will run fastest.
     const int take = p.lane_cap;                 // slots per refill: 64, fewer in an underfilled launch
-    int first_pool = cold_of(p).first_pools ? ((int)blockIdx.x * (int)((blockDim.x + 63) >> 6) + (int)(threadIdx.x >> 6)) * take : -1;
+    int first_pool = -1, first_take = take;
+    bool solo = false;                           // wave-uniform (SOLO kernels): this wave holds only its share of the heaviest pixels
+    bool takes_pixels = (int)(threadIdx.x & 63u) < p.lane_cap;
+    if (SOLO) {
+        // ColdParams::solo_*: wave 0 of the first solo_waves workgroups takes solo_lanes of the top-ranked pixels and
+        // nothing else until they are done; the other waves number their first pools without it.
+        const auto& c = cold_of(p);
+        const int wpb = (int)((blockDim.x + 63) >> 6), w = (int)(threadIdx.x >> 6), b = (int)blockIdx.x;
+        const int ns = c.solo_waves, sl = c.solo_lanes;
+        if (w == 0 && b < ns) {
+            first_pool = b * sl; first_take = sl; solo = true;
+            takes_pixels = (int)(threadIdx.x & 63u) < sl;
+        } else {
+            first_pool = ns * sl + (b * wpb + w - (b < ns ? b + 1 : ns)) * take;
+        }
+    } else if (cold_of(p).first_pools) {
+        first_pool = ((int)blockIdx.x * (int)((blockDim.x + 63) >> 6) + (int)(threadIdx.x >> 6)) * take;
+    }
     unsigned long long t_start = 0, t_exh = 0;
     unsigned int it_normal = 0, it_coop = 0, n_pixels = 0;
     if (COUNT) t_start = __builtin_amdgcn_s_memrealtime();
-    const bool takes_pixels = (int)(threadIdx.x & 63u) < p.lane_cap;
     const int lanes_left = (int)blockDim.x - (int)(threadIdx.x & ~63u);
     const int wave_lanes = lanes_left < 64 ? lanes_left : 64;   // partial last wave of a T x T block
 
     for (;;) {
         REGION_BEGIN(total);
         REGION_BEGIN(refill);
-        if (!exhausted && __builtin_amdgcn_ballot_w64(!alive && takes_pixels) != 0) {
+        if (SOLO && solo && first_pool < 0 && __builtin_amdgcn_ballot_w64(alive) == 0) {   // the solo pixels are done: an ordinary wave from here on
+            solo = false;
+            takes_pixels = (int)(threadIdx.x & 63u) < p.lane_cap;
+        }
+        if (!exhausted && !(SOLO && solo && first_pool < 0) && __builtin_amdgcn_ballot_w64(!alive && takes_pixels) != 0) {
             bool want = !alive && takes_pixels;
             PATH_STAT(PS_REFILL);
             const auto& c = cold_of(p);          // image / shard geometry and buffers: scalar loads here, not live in the path loop
@@ -1273,16 +1296,16 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
                 if (m == 0) break;
                 if (pool_next >= pool_end) {     // refill the wave's pool: one atomic per 64 pixels
-                    int base = 0;
+                    int base = 0, this_take = take;
                     if (first_pool >= 0) {       // the first pool follows dispatch order (= wave age), see launch_render
-                        base = first_pool;
+                        base = first_pool; this_take = first_take;
                         first_pool = -1;
                     } else {
                         if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) base = (int)atomicAdd(c.work_counter, (unsigned)take);
                         base = __builtin_amdgcn_readfirstlane(base);
                     }
                     if (base >= total_slots) { exhausted = true; if (COUNT) t_exh = __builtin_amdgcn_s_memrealtime(); break; }
-                    pool_next = base; pool_end = base + take;
+                    pool_next = base; pool_end = base + this_take;
                 }
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 const int avail = pool_end - pool_next;
@@ -1343,7 +1366,7 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
         const bool need_hit = alive && st.depth < p.B;
         T closest = __builtin_huge_val();
         int hit = -1;
-        bool share_loops = (exhausted || 2 * p.lane_cap <= wave_lanes) && 2 * __builtin_popcountll(alive_mask) <= wave_lanes;
+        bool share_loops = (exhausted || (SOLO && solo) || 2 * p.lane_cap <= wave_lanes) && 2 * __builtin_popcountll(alive_mask) <= wave_lanes;
         const unsigned long long hit_mask = __builtin_amdgcn_ballot_w64(need_hit);
         if (share_loops && p.use_grid && hit_mask != 0) {
             // With a grid, sharing the brute-force loop only pays while a ray's share of it is short: g lanes per
@@ -1422,6 +1445,11 @@ template <class T, int SRC, bool COUNT>
 __global__ void __launch_bounds__(1024) render_persistent_kernel(const RenderParams<T> p) { persistent_body<T, SRC, COUNT>(p); }
 template <class T, int SRC, bool COUNT>
 __global__ void __launch_bounds__(1024) render_prepass_kernel(const RenderParams<T> p) { persistent_body<T, SRC, COUNT>(p); }
+// The main launch of a partly filled GPU (small frame, shard of a multi-GPU frame): the same body with the solo
+// waves of ColdParams::solo_* compiled in (a kernel of its own, so that the full-frame launch does not carry the
+// wave-uniform bookkeeping: +1 % measured).
+template <class T, int SRC>
+__global__ void __launch_bounds__(1024) render_solo_kernel(const RenderParams<T> p) { persistent_body<T, SRC, false, true>(p); }
 
 // Elementwise arithmetic probes (tests compare these with the host bit for bit).
 template <class T>
@@ -1522,7 +1550,8 @@ __global__ void __launch_bounds__(COST_BINS) cost_scan_kernel(const unsigned* __
 // (2 M contended global atomics on ~20 hot bins took 17.8 ms; this takes microseconds).
 constexpr int SCATTER_PER_THREAD = 4;
 __global__ void __launch_bounds__(1024) cost_scatter_kernel(const uint32_t* __restrict__ cost, int W, int rows, const unsigned* __restrict__ start,
-                                                            unsigned* __restrict__ fill, int* __restrict__ order, int pools_per_block, int total_pools, int group) {
+                                                            unsigned* __restrict__ fill, int* __restrict__ order, int pools_per_block, int total_pools, int group,
+                                                            int solo_slots) {
     __shared__ unsigned local[COST_BINS];        // block histogram, then the running rank inside the reserved range
     __shared__ unsigned base[COST_BINS];
     for (int b = threadIdx.x; b < COST_BINS; b += blockDim.x) local[b] = 0;
@@ -1556,13 +1585,15 @@ __global__ void __launch_bounds__(1024) cost_scatter_kernel(const uint32_t* __re
     for (int u = 0; u < SCATTER_PER_THREAD; ++u) {
         if (bins[u] < 0) continue;
         const int k = pix[u];
-        const int r = (int)(base[bins[u]] + atomicAdd(&local[bins[u]], 1u));   // sorted rank (order inside a bin is immaterial)
+        int r = (int)(base[bins[u]] + atomicAdd(&local[bins[u]], 1u));   // sorted rank (order inside a bin is immaterial)
+        if (r < solo_slots) { order[r] = k; continue; }              // the heaviest pixels: slot = rank, handed to the solo waves
+        r -= solo_slots;
         const int blk = r / per_block, q = r - blk * per_block;
         const int pools_here = (blk + 1) * pools_per_block <= total_pools ? pools_per_block : total_pools - blk * pools_per_block;
         const int g = q / group, j = q - g * group;                 // groups of `group` consecutive ranks stay together
         const int pool = blk * pools_per_block + g % pools_here;
         const int lane_slot = (g / pools_here) * group + j;
-        order[pool * POOL + lane_slot] = k;
+        order[solo_slots + pool * POOL + lane_slot] = k;
     }
 }
 
@@ -2157,6 +2188,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         p.cold.work_counter = h->work_counter;
         p.cold.s_begin = 0; p.s_end = S; p.cold.rng_in = h->rng; p.cold.mid_in = nullptr; p.cold.mid_out = nullptr;
         p.cold.cost_out = nullptr; p.cold.order = nullptr; p.cold.total_slots = (int)tile_slots; p.cold.first_pools = 0;
+        p.cold.solo_waves = 0; p.cold.solo_lanes = 1;
         if (h->schedule == RTIOW_SCHED_SORTED && SA > 0 && npix >= 4096) {
             phases = 2;
             const int total_pools = (npix + POOL - 1) / POOL;
@@ -2164,7 +2196,34 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             if ((rc = ensure_buffer(h, &h->mid, &h->mid_bytes, (size_t)npix * sizeof(MidState<T>)))) return rc;
             if ((rc = ensure_buffer(h, &h->cost, &h->cost_bytes, (size_t)npix * sizeof(uint32_t)))) return rc;
             if ((rc = ensure_buffer(h, &h->cost_rank, &h->cost_rank_bytes, (size_t)npix * sizeof(uint32_t)))) return rc;
-            if ((rc = ensure_buffer(h, &h->order, &h->order_bytes, (size_t)total_pools * POOL * sizeof(int)))) return rc;
+            // Solo waves (ColdParams::solo_*, render_solo_kernel).  A shard or small frame ends with its longest sample
+            // chains (one pixel = one sequential chain), and a chain advances at the pace of its wave: 2452 segments at
+            // ~3 us per trip among 63 other pixels.  Two heavy pixels alone in a wave share every sphere loop with the
+            // idle lanes and skip the divergent work of wave-mates.  Which pixels: the top of the cost ranking.  How
+            // many waves: more than ~5 % of the resident waves cost more throughput than the chains gain; measured per
+            // fill level (profiles/r02_handout_study/): 1/8 frame 6.96 -> 5.65 ms with 128 waves (5.78 with 256),
+            // 1/4 frame 7.85 -> 6.61 with 256 (7.03 with 128), 1/2 frame 8.43 -> 8.21, 1280x720 8.82 -> 8.34; the full
+            // frame (6.3 pools per wave) loses 1-2 % and keeps the plain kernel.  Scene 1 at 25 bounces has no outlier
+            // chains and pays 1-4 % at these fill levels.
+            const double fill_level = (double)total_pools / (double)(blocks * waves_per_block);
+            int solo_waves = seg_counter ? 0 : (fill_level < 1.2 ? 128 : (fill_level < 4.0 ? 256 : 0)), solo_lanes = 2;
+#ifdef RTIOW_TUNING
+            if (const char* e = std::getenv("RTIOW_TUNE_SOLO_WAVES")) solo_waves = std::atoi(e);
+            if (const char* e = std::getenv("RTIOW_TUNE_SOLO_LANES")) solo_lanes = std::atoi(e);
+#endif
+            if (solo_lanes < 1) solo_lanes = 1;
+            RenderFn<T> k_solo = lds_source ? (RenderFn<T>)render_solo_kernel<T, RTIOW_SCENE_LDS> : (RenderFn<T>)render_solo_kernel<T, RTIOW_SCENE_SCALAR>;
+            if (solo_waves > 0) {
+                if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)k_solo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                int per_cu_solo = 0;
+                HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_solo, (const void*)k_solo, threads, lds));
+                if ((long long)per_cu_solo * h->num_cus < blocks) solo_waves = 0;   // its workgroups must all be resident, as the first pools assume
+            }
+            if (solo_lanes > lane_cap) solo_lanes = lane_cap;
+            if (solo_waves > (int)blocks) solo_waves = (int)blocks;
+            if ((long long)solo_waves * solo_lanes > npix / 2) solo_waves = npix / 2 / solo_lanes;
+            const int solo_slots = solo_waves * solo_lanes;
+            if ((rc = ensure_buffer(h, &h->order, &h->order_bytes, ((size_t)total_pools * POOL + (size_t)solo_slots) * sizeof(int)))) return rc;
             if ((rc = ensure_buffer(h, &h->sort_scratch, &h->sort_scratch_bytes, (size_t)3 * COST_BINS * sizeof(unsigned)))) return rc;
             if (prepare_only) return 0;                  // every table and buffer of this configuration now exists
             // ---- prepass: samples [0, SA) in tile order through the same persistent body (the static
@@ -2183,7 +2242,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             // Blocks of the order are one "age class" of resident waves wide (see first_pools).
             unsigned* hist = h->sort_scratch; unsigned* start = hist + COST_BINS; unsigned* fill = start + COST_BINS;
             HIP_TRY(h, hipMemsetAsync(hist, 0, COST_BINS * sizeof(unsigned), h->stream));
-            HIP_TRY(h, hipMemsetAsync(h->order, 0xff, (size_t)total_pools * POOL * sizeof(int), h->stream));
+            HIP_TRY(h, hipMemsetAsync(h->order, 0xff, ((size_t)total_pools * POOL + (size_t)solo_slots) * sizeof(int), h->stream));
             const int sort_blocks = (npix + 255) / 256;
             const uint32_t* rank_by = h->cost;
             int smooth_hw = 6;                          // 13 x 13 window: profiles/r02_cost_smoothing_sweep.jsonl
@@ -2218,20 +2277,26 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
 #endif
             const int scatter_blocks = ((p.cold.W + 63) / 64) * ((h->local_rows + 63) / 64);   // one per 64 x 64 super-tile
             hipLaunchKernelGGL(cost_scatter_kernel, dim3(scatter_blocks), dim3(1024), 0, h->stream, rank_by, p.cold.W, h->local_rows, start, fill, h->order,
-                               pools_per_block, total_pools, deal_group);
+                               pools_per_block, total_pools, deal_group, solo_slots);
             HIP_TRY(h, hipGetLastError());
             // ---- main launch: samples [SA, S) in that order
             p.cold.s_begin = SA; p.cold.mid_in = h->mid; p.cold.order = h->order;
-            p.cold.total_slots = total_pools * POOL;
+            p.cold.total_slots = solo_slots + total_pools * POOL;
             p.cold.work_counter = h->work_counter + 1;
             p.cold.first_pools = 1;
-            const unsigned counter_start = (unsigned)resident_waves * (unsigned)lane_cap;
+            p.cold.solo_waves = solo_waves; p.cold.solo_lanes = solo_lanes;
+            if (solo_waves > 0) {
+                k = k_solo;
+                HIP_TRY(h, hipFuncGetAttributes(&fa, (const void*)k));
+            }
+            const unsigned counter_start = (unsigned)solo_slots + (unsigned)(resident_waves - solo_waves) * (unsigned)lane_cap;
             HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)(h->work_counter + 1), (int)counter_start, 1, h->stream));
         }
     } else {
         grid = dim3((p.cold.W + bx - 1) / bx, (h->local_rows + by - 1) / by);
         p.cold.s_begin = 0; p.s_end = p.cold.S; p.cold.rng_in = h->rng; p.cold.mid_in = nullptr; p.cold.mid_out = nullptr;
         p.cold.cost_out = nullptr; p.cold.order = nullptr; p.cold.total_slots = 0; p.cold.first_pools = 0; p.cold.work_counter = nullptr;
+        p.cold.solo_waves = 0; p.cold.solo_lanes = 1;
     }
     if (prepare_only) return 0;
     if (seg_counter) {
@@ -2253,6 +2318,8 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         h->stats.grid_blocks = (int)(grid.x * grid.y);
         h->stats.phases = phases;
         if (phases == 1) h->stats.prepass_samples = 0;
+        h->stats.solo_waves = phases == 2 ? p.cold.solo_waves : 0;
+        h->stats.solo_lanes = phases == 2 && p.cold.solo_waves > 0 ? p.cold.solo_lanes : 0;
     }
     return 0;
 }

@@ -692,6 +692,35 @@ def test_baseline_config5_fp64_500spp_and_float_vs_double(rt, oracle, tmp_path):
     assert np.all(np.abs(lf.mean(axis=(0, 1)) - ld.mean(axis=(0, 1))) < 0.6)
 
 
+@pytest.mark.parametrize("prec,scene_id,W,H,S,B,shard", [
+    (32, 3, 640, 360, 32, 50, None),          # 0.7 pools per wave: 128 solo waves
+    (64, 3, 640, 360, 32, 50, None),
+    (32, 3, 1920, 1080, 24, 50, (1, 4, 2)),   # a quarter of the headline frame in 2-row strips: 256 solo waves
+    (32, 1, 64, 64, 24, 25, None),            # the smallest frame the sorted schedule sorts: solo waves clamped to the 64 workgroups
+    (32, 2, 200, 100, 64, 50, None),          # scene 2 (4 spheres)
+])
+def test_solo_waves_leave_the_image_alone(rt, oracle, prec, scene_id, W, H, S, B, shard):
+    """On a partly filled GPU the main launch of the sorted schedule is render_solo_kernel: the top-ranked pixels
+    two per wave.  A schedule only: same image as the static schedule (one lane per pixel, no hand-out at all),
+    bit for bit, and as the oracle on a few rows."""
+    sc = rt.build_scene(scene_id, prec)
+    with rt.Renderer(0, prec) as r:
+        r.set_camera(rt.camera(prec, W, H, S, B)); r.set_scene(sc)
+        if shard:
+            r.set_shard(*shard)
+        r.init_rng(1227)
+        r.render(0)
+        got = r.read_framebuffer()
+        st = r.stats()
+    assert st["phases"] == 2 and st["solo_waves"] > 0 and st["solo_lanes"] == 2, st
+    assert st["solo_waves"] == min(256 if shard else 128, st["grid_blocks"]), st
+    assert _same_bits(got, _render(rt, prec, scene_id, W, H, S, B, threads=8, shard=shard, sched=rt.SCHED_STATIC))
+    if not shard:
+        for row in (0, H // 2, H - 1):
+            want, _ = _oracle(oracle, rt, prec, scene_id, W, H, S, B, rows=(row, row + 1))
+            assert _same_bits(got[row:row + 1], want), row
+
+
 def test_full_size_properties(rt, oracle):
     """BASELINE headline config (scene 3, 1920x1080, 100 spp, 50 bounces): too big for the
     oracle in full, so: (1) run-to-run determinism, (2) 8-way sharded == whole image,
@@ -704,6 +733,7 @@ def test_full_size_properties(rt, oracle):
         a = r.read_framebuffer()
         r.render(8)
         b = r.read_framebuffer()
+        assert r.stats()["solo_waves"] == 0          # a full GPU keeps the plain kernel
         segs = r.count_segments(0)
     assert _same_bits(a, b)
     # the fp32 screen in front of the exact sphere test (default) vs the exact test on every
