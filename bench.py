@@ -331,13 +331,14 @@ def main():
                          "issued": pmc_issue(args) if world == 1 else None},
             "step": {"launches": "prepass (%d spp) + cost sort + main" % st["prepass_samples"] if st["phases"] == 2 else "main",
                      "kernel_ms_mean": round(kms, 4), "prepass_ms": round(float(st["prepass_ms"]), 4),
+                     "solo_waves": int(st["solo_waves"]),   # > 0: a partly filled GPU (shard, small frame), render_solo_kernel
                      "algorithmic_flops": flops_step, "achieved_TFLOPs": round(flops_step / (kms * 1e-3) / 1e12, 3),
                      "frac_of_peak": round(flops_step / (kms * 1e-3) / 1e12 / peak, 4)},
         }
         line["scaling_detail"] = {
             "floor_ms": round(floor_ms, 4), "floor_is": "prepass_ms + longest per-pixel chain of the main launch x the trip latency of a lone ray on an idle GPU (1-pixel probe), max over ranks: "
-                                                                "what a rank reaches if its longest chain runs undisturbed from the first trip; shards run it at about twice that "
-                                                                "latency because the SIMDs stay loaded with sparse waves (DESIGN.md section 5)",
+                                                                "what a rank reaches if its longest chain runs undisturbed from the first trip; shards run it at 1.6-2x that "
+                                                                "latency, two heavy pixels per solo wave beside the loaded SIMDs (DESIGN.md sections 4.3, 5)",
             "longest_chain_segments": chain_max, "lone_ray_trip_us": round(trip_us, 4) if trip_us else None,
             "lone_ray_probe": "1x1 frame, 400 spp, %d segments" % trip_segments,
             "kernel_ms_per_rank": kernel_ms_per_rank, "gather_ms_per_rank": gather_ms_per_rank,

@@ -1,4 +1,4 @@
-"""Every rank's shard timed for strip heights 8/4/2/1 at N = 2/4/8 on ONE GPU (profiles/r01_strip_rows_sweep.txt)."""
+"""Every rank's shard timed for strip heights 8/4/2/1 at N = 2/4/8 on ONE GPU (profiles/r01_strip_rows_sweep.txt, profiles/r02_strip_rows_sweep.jsonl)."""
 import json, sys
 import numpy as np
 sys.path.insert(0, '.')
