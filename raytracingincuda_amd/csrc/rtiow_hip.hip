@@ -2203,10 +2203,11 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             // many waves: more than ~5 % of the resident waves cost more throughput than the chains gain; measured per
             // fill level (profiles/r02_handout_study/): 1/8 frame 6.96 -> 5.65 ms with 128 waves (5.78 with 256),
             // 1/4 frame 7.85 -> 6.61 with 256 (7.03 with 128), 1/2 frame 8.43 -> 8.21, 1280x720 8.82 -> 8.34; the full
-            // frame (6.3 pools per wave) loses 1-2 % and keeps the plain kernel.  Scene 1 at 25 bounces has no outlier
-            // chains and pays 1-4 % at these fill levels.
+            // frame (6.3 pools per wave) loses 1-2 % and keeps the plain kernel.  Outlier chains need a bounce limit
+            // that lets rare long paths exist: at 10 bounces the solo waves cost 4-11 % on both scenes, at 25 scene 3
+            // gains 9 % and scene 1 is even (+2 % / -4 %), from 50 on both gain (sweep6_bounce_limit.txt).
             const double fill_level = (double)total_pools / (double)(blocks * waves_per_block);
-            int solo_waves = seg_counter ? 0 : (fill_level < 1.2 ? 128 : (fill_level < 4.0 ? 256 : 0)), solo_lanes = 2;
+            int solo_waves = (seg_counter || p.B < 20) ? 0 : (fill_level < 1.2 ? 128 : (fill_level < 4.0 ? 256 : 0)), solo_lanes = 2;
 #ifdef RTIOW_TUNING
             if (const char* e = std::getenv("RTIOW_TUNE_SOLO_WAVES")) solo_waves = std::atoi(e);
             if (const char* e = std::getenv("RTIOW_TUNE_SOLO_LANES")) solo_lanes = std::atoi(e);
