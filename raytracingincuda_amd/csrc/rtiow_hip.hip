@@ -2205,9 +2205,10 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             // 1/4 frame 7.85 -> 6.61 with 256 (7.03 with 128), 1/2 frame 8.43 -> 8.21, 1280x720 8.82 -> 8.34; the full
             // frame (6.3 pools per wave) loses 1-2 % and keeps the plain kernel.  Outlier chains need a bounce limit
             // that lets rare long paths exist: at 10 bounces the solo waves cost 4-11 % on both scenes, at 25 scene 3
-            // gains 9 % and scene 1 is even (+2 % / -4 %), from 50 on both gain (sweep6_bounce_limit.txt).
+            // gains 9 % and scene 1 -- the reference's own benchmark grid -- loses 2-5 %, from 50 on both gain
+            // (sweep6_bounce_limit.txt): the rule asks for more than 32.
             const double fill_level = (double)total_pools / (double)(blocks * waves_per_block);
-            int solo_waves = (seg_counter || p.B < 20) ? 0 : (fill_level < 1.2 ? 128 : (fill_level < 4.0 ? 256 : 0)), solo_lanes = 2;
+            int solo_waves = (seg_counter || p.B < 32) ? 0 : (fill_level < 1.2 ? 128 : (fill_level < 4.0 ? 256 : 0)), solo_lanes = 2;
 #ifdef RTIOW_TUNING
             if (const char* e = std::getenv("RTIOW_TUNE_SOLO_WAVES")) solo_waves = std::atoi(e);
             if (const char* e = std::getenv("RTIOW_TUNE_SOLO_LANES")) solo_lanes = std::atoi(e);

@@ -703,7 +703,7 @@ def test_baseline_config5_fp64_500spp_and_float_vs_double(rt, oracle, tmp_path):
     (32, 3, 640, 360, 32, 50, None),          # 0.7 pools per wave: 128 solo waves
     (64, 3, 640, 360, 32, 50, None),
     (32, 3, 1920, 1080, 24, 50, (1, 4, 2)),   # a quarter of the headline frame in 2-row strips: 256 solo waves
-    (32, 1, 64, 64, 24, 25, None),            # the smallest frame the sorted schedule sorts: solo waves clamped to the 64 workgroups
+    (32, 1, 64, 64, 24, 40, None),            # the smallest frame the sorted schedule sorts: solo waves clamped to the 64 workgroups
     (32, 2, 200, 100, 64, 50, None),          # scene 2 (4 spheres)
 ])
 def test_solo_waves_leave_the_image_alone(rt, oracle, prec, scene_id, W, H, S, B, shard):
