@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -285,11 +286,12 @@ int main(int argc, char** argv) {
     // .ppm output (main.cu:347-379)
     char name[256];
     rtiow_host_ppm_filename(precision, opt.scene_id, opt.width, opt.height, opt.samples, opt.bounces, opt.threads, name, sizeof name);
-    std::vector<unsigned char> rgb(elem * 3 * (size_t)opt.width * opt.height);
-    check(h, rtiow_read_framebuffer(h, rgb.data(), rgb.size()));
+    const size_t rgb_bytes = elem * 3 * (size_t)opt.width * opt.height;
+    const std::unique_ptr<unsigned char[]> rgb(new unsigned char[rgb_bytes]);   // not zero-filled: every byte is read back
+    check(h, rtiow_read_framebuffer(h, rgb.get(), rgb_bytes));
     const double t_read = lap();
-    const int wrc = opt.binary_ppm ? rtiow_host_write_ppm_binary(name, precision, opt.width, opt.height, rgb.data())
-                                   : rtiow_host_write_ppm(name, precision, opt.width, opt.height, rgb.data());
+    const int wrc = opt.binary_ppm ? rtiow_host_write_ppm_binary(name, precision, opt.width, opt.height, rgb.get())
+                                   : rtiow_host_write_ppm(name, precision, opt.width, opt.height, rgb.get());
     if (wrc != 0) {
         std::fprintf(stderr, "Error: Could not open file for writing: %s\n", name);
         return -1;
@@ -300,6 +302,7 @@ int main(int argc, char** argv) {
     std::memset(&st, 0, sizeof st);
     rtiow_get_stats(h, &st);
     check(h, rtiow_destroy(h));                                              // main.cu:384-391
+    const double t_destroy = lap();
     const auto e2e_stop = std::chrono::steady_clock::now();                  // main.cu:394
     const double e2e_ms = std::chrono::duration<double, std::milli>(e2e_stop - e2e_start).count();
     std::printf("%15.8f\n", e2e_ms);
@@ -309,10 +312,10 @@ int main(int argc, char** argv) {
         std::fprintf(stderr,
                      "{\"mrays_per_s\": %.3f, \"render_ms\": %.6f, \"rng_init_ms\": %.6f, \"spheres\": %d, \"block\": [%d, %d], "
                      "\"vgprs\": %d, \"lds_bytes\": %d, \"scene_source\": \"%s\", \"solo_waves\": %d, "
-                     "\"wall_ms\": {\"setup\": %.3f, \"rng_init\": %.3f, \"render\": %.3f, \"readback\": %.3f, \"ppm_write\": %.3f, \"end_to_end\": %.3f}}\n",
+                     "\"wall_ms\": {\"setup\": %.3f, \"rng_init\": %.3f, \"render\": %.3f, \"readback\": %.3f, \"ppm_write\": %.3f, \"destroy\": %.3f, \"end_to_end\": %.3f}}\n",
                      render_ms > 0 ? rays / render_ms / 1e3 : 0.0, (double)render_ms, st.rng_init_ms, st.num_spheres,
                      st.block_x, st.block_y, st.vgprs, st.lds_bytes, st.scene_source == RTIOW_SCENE_GRID ? "grid" : (st.scene_source == RTIOW_SCENE_SCALAR ? "scalar" : "lds"), st.solo_waves,
-                     t_setup, t_rng, t_render, t_read, t_write, e2e_ms);
+                     t_setup, t_rng, t_render, t_read, t_write, t_destroy, e2e_ms);
     }
     return 0;
 }

@@ -37,6 +37,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "rtiow.h"
@@ -1604,9 +1605,11 @@ struct Mat160 { uint32_t col[XW_BITS][XW_WORDS]; };
 
 void mat_vec(const Mat160& m, const uint32_t* in, uint32_t* out) {
     uint32_t acc[XW_WORDS] = {0, 0, 0, 0, 0};
-    for (int b = 0; b < XW_BITS; ++b)
-        if ((in[b >> 5] >> (b & 31)) & 1u)
-            for (int k = 0; k < XW_WORDS; ++k) acc[k] ^= m.col[b][k];
+    for (int w = 0; w < XW_WORDS; ++w)
+        for (uint32_t bits = in[w]; bits; bits &= bits - 1) {          // the set bits only
+            const uint32_t* c = m.col[w * 32 + __builtin_ctz(bits)];
+            for (int k = 0; k < XW_WORDS; ++k) acc[k] ^= c[k];
+        }
     std::memcpy(out, acc, sizeof acc);
 }
 
@@ -1614,11 +1617,12 @@ void mat_vec(const Mat160& m, const uint32_t* in, uint32_t* out) {
 // built by pushing the 160 basis vectors through the generator).  A^(2^67) is a committed constant
 // (xorwow_jump67.inc, written by gen/gen_xorwow_jump67.cpp), so a process pays 31 squarings instead
 // of 98; `from_scratch` derives everything from A and is what the tests compare the constant with.
+// `count` = how many of the 32 to build: rng_init_kernel reads matrix b only when bit b of a pixel index is set.
 const uint32_t kJump67[XW_BITS * XW_WORDS] = {
 #include "xorwow_jump67.inc"
 };
 
-std::vector<uint32_t> build_sequence_jump_matrices(bool from_scratch = false) {
+std::vector<uint32_t> build_sequence_jump_matrices(bool from_scratch = false, int count = XW_JUMPS) {
     Mat160 cur, nxt;
     int done = 0;
     if (from_scratch) {
@@ -1634,10 +1638,10 @@ std::vector<uint32_t> build_sequence_jump_matrices(bool from_scratch = false) {
         done = 67;
     }
     std::vector<uint32_t> out;
-    out.reserve(XW_JUMPS * XW_MAT_WORDS);
-    for (int e = done; e < 67 + XW_JUMPS; ++e) {
+    out.reserve((size_t)count * XW_MAT_WORDS);
+    for (int e = done; e < 67 + count; ++e) {
         if (e >= 67) out.insert(out.end(), &cur.col[0][0], &cur.col[0][0] + XW_MAT_WORDS);
-        if (e + 1 == 67 + XW_JUMPS) break;
+        if (e + 1 == 67 + count) break;
         for (int b = 0; b < XW_BITS; ++b) mat_vec(cur, cur.col[b], nxt.col[b]);
         cur = nxt;
     }
@@ -1680,6 +1684,7 @@ struct rtiow_handle_s {
     size_t rng_pixels = 0;
     bool rng_ready = false;
     uint32_t* jump = nullptr;
+    int jump_count = 0;                           // matrices of `jump` that are filled: enough for the bits of the largest pixel index so far
     // framebuffer
     void* fb = nullptr;
     size_t fb_bytes = 0;
@@ -2357,6 +2362,32 @@ int rtiow_debug_path_stats(unsigned long long* out, int cap_words, int reset) {
 }
 #endif
 
+// Streams of destroyed handles are kept for the next rtiow_create on the same device instead of being destroyed:
+// hipStreamDestroy tears down a hardware queue (~3 ms, most of what rtiow_destroy took inside the executables'
+// end-to-end time); the runtime releases the idle ones at process exit.
+namespace {
+std::mutex g_idle_streams_mu;
+std::vector<std::pair<int, hipStream_t>> g_idle_streams;
+
+hipError_t acquire_stream(int device, hipStream_t* out) {
+    {
+        std::lock_guard<std::mutex> lock(g_idle_streams_mu);
+        for (size_t k = 0; k < g_idle_streams.size(); ++k)
+            if (g_idle_streams[k].first == device) {
+                *out = g_idle_streams[k].second;
+                g_idle_streams.erase(g_idle_streams.begin() + (long)k);
+                return hipSuccess;
+            }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void release_stream(int device, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_idle_streams_mu);
+    g_idle_streams.emplace_back(device, s);
+}
+}  // namespace
+
 int rtiow_create(int device, int precision, rtiow_handle* out) {
     if (!out || (precision != 32 && precision != 64)) return RTIOW_E_BADARG;
     *out = nullptr;
@@ -2368,9 +2399,11 @@ int rtiow_create(int device, int precision, rtiow_handle* out) {
     if (!h) return RTIOW_E_NOMEM;
     h->device = device; h->precision = precision;
     if ((e = hipSetDevice(device)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = acquire_stream(device, &h->stream)) != hipSuccess ||
         (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess ||
         (e = hipEventCreate(&h->ev_a)) != hipSuccess || (e = hipEventCreate(&h->ev_b)) != hipSuccess) {
+        for (hipEvent_t ev : {h->ev0, h->ev1, h->ev_a, h->ev_b}) if (ev) (void)hipEventDestroy(ev);
+        if (h->stream) release_stream(device, h->stream);
         delete h;
         return (int)e;
     }
@@ -2410,7 +2443,7 @@ int rtiow_destroy(rtiow_handle h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_a) (void)hipEventDestroy(h->ev_a);
     if (h->ev_b) (void)hipEventDestroy(h->ev_b);
-    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream && h->stream) release_stream(h->device, h->stream);     // synchronised above
     delete h;
     return 0;
 }
@@ -2420,7 +2453,7 @@ const char* rtiow_last_error_string(rtiow_handle h) { return h ? h->err.c_str() 
 int rtiow_set_stream(rtiow_handle h, void* hip_stream) {
     if (!h) return RTIOW_E_BADARG;
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->own_stream && h->stream) { HIP_TRY(h, hipStreamSynchronize(h->stream)); HIP_TRY(h, hipStreamDestroy(h->stream)); }
+    if (h->own_stream && h->stream) { HIP_TRY(h, hipStreamSynchronize(h->stream)); release_stream(h->device, h->stream); }
     h->stream = (hipStream_t)hip_stream;
     h->own_stream = false;
     return 0;
@@ -2476,12 +2509,15 @@ int rtiow_init_rng(rtiow_handle h, uint64_t seed) {
     if (!h) return RTIOW_E_BADARG;
     if (!h->have_camera) return fail_arg(h, RTIOW_E_STATE, "rtiow_init_rng before rtiow_set_camera");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (!h->jump) {
-        std::vector<uint32_t> m = build_sequence_jump_matrices();
-        HIP_TRY(h, hipMalloc((void**)&h->jump, m.size() * sizeof(uint32_t)));
-        HIP_TRY(h, hipMemcpy(h->jump, m.data(), m.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    }
     const int W = img_w(h), H = img_h(h);
+    int index_bits = 1;                                      // bits of the largest GLOBAL pixel index W*H-1
+    while (index_bits < XW_JUMPS && ((uint64_t)W * (uint64_t)H - 1) >> index_bits) ++index_bits;
+    if (h->jump_count < index_bits) {                        // 31 squarings for all 32 matrices take 2.4 ms on the host; a 1080p frame needs 21
+        std::vector<uint32_t> m = build_sequence_jump_matrices(false, index_bits);
+        if (!h->jump) HIP_TRY(h, hipMalloc((void**)&h->jump, (size_t)XW_JUMPS * XW_MAT_WORDS * sizeof(uint32_t)));
+        HIP_TRY(h, hipMemcpy(h->jump, m.data(), m.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        h->jump_count = index_bits;
+    }
     const size_t npix = (size_t)W * h->local_rows;
     if (h->rng_pixels < npix) {
         if (h->rng) { HIP_TRY(h, hipFree(h->rng)); h->rng = nullptr; h->rng_pixels = 0; }
