@@ -12,7 +12,14 @@ spec = os.environ.get("SWEEP_CASES", "off:;solo256x2:SOLO_WAVES=256,SOLO_LANES=2
 cases = []
 for c in spec.split(";"):
     name, _, kv = c.partition(":")
-    cases.append((name, {"RTIOW_TUNE_" + k.split("=")[0]: k.split("=")[1] for k in kv.split(",") if k}))
+    env, key = {}, None
+    for tok in kv.split(","):                      # a token without "=" continues the previous value (comma-separated lists)
+        if "=" in tok:
+            key = "RTIOW_TUNE_" + tok.split("=")[0]
+            env[key] = tok.split("=", 1)[1]
+        elif tok and key:
+            env[key] += "," + tok
+    cases.append((name, env))
 times = {c[0]: [] for c in cases}
 md5 = {}
 for rd in range(2):
