@@ -195,6 +195,10 @@ int rtiow_device(rtiow_handle h, int* device);
  * parity tests compare bit-for-bit with the host (op: 0 a/b, 1 sqrt(a), 2 fma(a,b,c),
  * 3 uniform(u32 a -> T), 4 a*b+c unfused). */
 int rtiow_debug_read_rng(rtiow_handle h, uint32_t* host_states, size_t count_words);
+/* After a render with RTIOW_SCHED_SORTED that sorted (rtiow_stats.phases == 2): per local pixel the prepass cost
+ * (path segments of its prepass samples) and the key the sort ranked it by (the mean of that cost over the
+ * pixel's neighbourhood inside its row strip, in quarter segments).  count = local pixels. */
+int rtiow_debug_read_costs(rtiow_handle h, uint32_t* own, uint32_t* smoothed, size_t count);
 /* Per-wave timeline of one (untimed, counting) persistent render: 8 words per wave
  * {t_start, t_pool_exhausted, t_end (100 MHz ticks), iterations alone, iterations cooperative,
  * pixels taken, 0, 0}. */

@@ -83,7 +83,7 @@ HIP_SYMBOLS = [
     "rtiow_set_scene", "rtiow_set_camera", "rtiow_set_shard", "rtiow_local_rows", "rtiow_local_row_map",
     "rtiow_init_rng", "rtiow_render", "rtiow_count_segments", "rtiow_bind_framebuffer", "rtiow_framebuffer_device_ptr",
     "rtiow_read_framebuffer", "rtiow_set_scene_source", "rtiow_set_schedule", "rtiow_get_stats", "rtiow_synchronize",
-    "rtiow_debug_read_rng", "rtiow_debug_timeline", "rtiow_debug_ops", "rtiow_debug_jump_matrices", "rtiow_debug_grid_plan", "rtiow_debug_hit_world",
+    "rtiow_debug_read_rng", "rtiow_debug_read_costs", "rtiow_debug_timeline", "rtiow_debug_ops", "rtiow_debug_jump_matrices", "rtiow_debug_grid_plan", "rtiow_debug_hit_world",
     "rtiow_render_async", "rtiow_render_wait", "rtiow_stream", "rtiow_device",
     "rtiow_group_create", "rtiow_group_create_error", "rtiow_group_destroy", "rtiow_group_last_error_string", "rtiow_group_size", "rtiow_group_member",
     "rtiow_group_set_scene", "rtiow_group_set_camera", "rtiow_group_set_scene_source", "rtiow_group_set_schedule",
@@ -159,6 +159,7 @@ def load_hip_library():
         lib.rtiow_get_stats.argtypes = [H, ctypes.POINTER(Stats)]
         lib.rtiow_synchronize.argtypes = [H]
         lib.rtiow_debug_read_rng.argtypes = [H, ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t]
+        lib.rtiow_debug_read_costs.argtypes = [H, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t]
         lib.rtiow_debug_timeline.argtypes = [H, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
         lib.rtiow_debug_ops.argtypes = [H, ctypes.c_int, ctypes.c_size_t, vp, vp, vp, vp]
         lib.rtiow_render_async.argtypes = [H, ctypes.c_int]
@@ -438,6 +439,14 @@ class Renderer:
         out = np.zeros((n, 6), np.uint32)
         self._check(self._lib.rtiow_debug_read_rng(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), out.size))
         return out
+
+    def debug_read_costs(self):
+        """(own, smoothed) prepass cost maps of the last sorted render, each local_rows x width."""
+        own = np.zeros((self.local_rows, self.width), np.uint32)
+        smoothed = np.zeros_like(own)
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        self._check(self._lib.rtiow_debug_read_costs(self._h, own.ctypes.data_as(u32p), smoothed.ctypes.data_as(u32p), own.size))
+        return own, smoothed
 
     def debug_timeline(self, threads=0):
         out = np.zeros((16384, 8), np.uint64)

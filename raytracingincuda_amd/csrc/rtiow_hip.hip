@@ -1500,23 +1500,52 @@ __device__ __forceinline__ int cost_bin(unsigned c) { return c < (unsigned)COST_
 // more than half of the frame's work); heavy pixels cluster -- the rims of the glass spheres, the crevices
 // between spheres -- and the 75 samples of a 5 x 5 neighbourhood predict it well (0.91; the same pixels then
 // start within the first 16 %).  Measured: headline 14.6 -> 13.5 ms, 1280x720 10.0 -> 8.6, half-frame shard
-// 10.6 -> 8.5, scene 1 26.0 -> 23.8 (hw = 6).  hw = half-width of the window.
+// 10.6 -> 8.5, scene 1 26.0 -> 23.8 (hw = 6).  hw = half-width of the window.  `strip_rows` = the rows that are
+// neighbours in the image: a rank's strip in a sharded frame (windows that cross into the rank's next strip, N x
+// strip rows away, rank the pixels worse: 1/4 frame 6.4 -> 7.2 ms), the whole frame on one rank (until the end of
+// round 2 the window stopped at the default 8-row strips there too: 1280x720 8.3 -> 7.9 ms, headline 13.4 -> 13.3,
+// profiles/r02_handout_study/sweep8_smoothing_window.txt; half-widths 5-10 are equal, sweep9).
+// One workgroup smooths a 64 x 16 tile from LDS: the tile with its halo, then the horizontal window sums of every
+// row it needs, then the vertical sums (26 LDS reads per pixel instead of 169 cached global loads: 61 -> 20 us on
+// the full frame).  Integer sums: the same values in any order.
+constexpr int SMOOTH_TW = 64, SMOOTH_TH = 16;
 __global__ void __launch_bounds__(256) cost_smooth_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ out, int W, int rows, int strip_rows, int hw) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= W * rows) return;
-    const int jl = k / W, i = k - jl * W;
-    const int s0 = (jl / strip_rows) * strip_rows;                                   // rows of other strips are not neighbours in the image
-    const int j0 = jl - hw > s0 ? jl - hw : s0;
-    int j1 = jl + hw < s0 + strip_rows - 1 ? jl + hw : s0 + strip_rows - 1;
-    if (j1 > rows - 1) j1 = rows - 1;
-    const int i0 = i - hw > 0 ? i - hw : 0, i1 = i + hw < W - 1 ? i + hw : W - 1;
-    unsigned sum = 0;
-    for (int j = j0; j <= j1; ++j)
-        for (int x = i0; x <= i1; ++x) sum += cost[j * W + x];
-    // mean over the window actually covered, in quarter segments: the bins keep their resolution at the image
-    // border and in two-row strips
-    const unsigned cells = (unsigned)((j1 - j0 + 1) * (i1 - i0 + 1));
-    out[k] = (4u * sum + cells / 2) / cells;
+    extern __shared__ uint32_t smooth_lds[];
+    const int halo_w = SMOOTH_TW + 2 * hw, halo_h = SMOOTH_TH + 2 * hw;
+    uint32_t* tile = smooth_lds;                       // [halo_h][halo_w], zero outside the image
+    uint32_t* hsum = smooth_lds + halo_w * halo_h;     // [halo_h][SMOOTH_TW]
+    const int tiles_x = (W + SMOOTH_TW - 1) / SMOOTH_TW;
+    const int tx = (int)blockIdx.x % tiles_x, ty = (int)blockIdx.x / tiles_x;
+    const int x_base = tx * SMOOTH_TW - hw, y_base = ty * SMOOTH_TH - hw;
+    for (int k = threadIdx.x; k < halo_w * halo_h; k += blockDim.x) {
+        const int ly = k / halo_w, lx = k - ly * halo_w;
+        const int x = x_base + lx, y = y_base + ly;
+        tile[k] = (x >= 0 && x < W && y >= 0 && y < rows) ? cost[y * W + x] : 0u;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < SMOOTH_TW * halo_h; k += blockDim.x) {
+        const int ly = k / SMOOTH_TW, lx = k - ly * SMOOTH_TW;
+        unsigned sum = 0;
+        for (int d = 0; d <= 2 * hw; ++d) sum += tile[ly * halo_w + lx + d];     // columns outside the image hold 0
+        hsum[k] = sum;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < SMOOTH_TW * SMOOTH_TH; k += blockDim.x) {
+        const int ly = k / SMOOTH_TW, lx = k - ly * SMOOTH_TW;
+        const int i = tx * SMOOTH_TW + lx, jl = ty * SMOOTH_TH + ly;
+        if (i >= W || jl >= rows) continue;
+        const int s0 = (jl / strip_rows) * strip_rows;                               // rows of other strips are not neighbours in the image
+        const int j0 = jl - hw > s0 ? jl - hw : s0;
+        int j1 = jl + hw < s0 + strip_rows - 1 ? jl + hw : s0 + strip_rows - 1;
+        if (j1 > rows - 1) j1 = rows - 1;
+        const int i0 = i - hw > 0 ? i - hw : 0, i1 = i + hw < W - 1 ? i + hw : W - 1;
+        unsigned sum = 0;
+        for (int j = j0; j <= j1; ++j) sum += hsum[(j - y_base) * SMOOTH_TW + lx];
+        // mean over the window actually covered, in quarter segments: the bins keep their resolution at the image
+        // border and in two-row strips
+        const unsigned cells = (unsigned)((j1 - j0 + 1) * (i1 - i0 + 1));
+        out[jl * W + i] = (4u * sum + cells / 2) / cells;
+    }
 }
 
 __global__ void __launch_bounds__(256) cost_hist_kernel(const uint32_t* __restrict__ cost, int npix, unsigned* __restrict__ hist) {
@@ -2257,7 +2286,15 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             if (const char* e = std::getenv("RTIOW_TUNE_SMOOTH")) smooth_hw = std::atoi(e);
 #endif
             if (smooth_hw > 0) {
-                hipLaunchKernelGGL(cost_smooth_kernel, dim3(sort_blocks), dim3(256), 0, h->stream, h->cost, h->cost_rank, p.cold.W, h->local_rows, h->strip_rows, smooth_hw);
+                if (smooth_hw > 24) smooth_hw = 24;      // 2 x (tile + halo) words of LDS: 37 KB at 24
+                const int smooth_blocks = ((p.cold.W + SMOOTH_TW - 1) / SMOOTH_TW) * ((h->local_rows + SMOOTH_TH - 1) / SMOOTH_TH);
+                const size_t smooth_lds_bytes = ((size_t)(SMOOTH_TW + 2 * smooth_hw) + SMOOTH_TW) * (size_t)(SMOOTH_TH + 2 * smooth_hw) * sizeof(uint32_t);
+                // one rank: its strips are adjacent in the image, the window may cross them (it did not before: 13 x <= 8 rows)
+                int window_strip = h->nranks == 1 ? (h->local_rows > 0 ? h->local_rows : 1) : h->strip_rows;
+#ifdef RTIOW_TUNING
+                if (const char* e = std::getenv("RTIOW_TUNE_SMOOTH_STRIP")) window_strip = std::atoi(e) > 0 ? std::atoi(e) : (h->local_rows > 0 ? h->local_rows : 1);
+#endif
+                hipLaunchKernelGGL(cost_smooth_kernel, dim3(smooth_blocks), dim3(256), smooth_lds_bytes, h->stream, h->cost, h->cost_rank, p.cold.W, h->local_rows, window_strip, smooth_hw);
                 rank_by = h->cost_rank;
             }
             hipLaunchKernelGGL(cost_hist_kernel, dim3(sort_blocks < 1024 ? sort_blocks : 1024), dim3(256), 0, h->stream, rank_by, npix, hist);
@@ -2725,6 +2762,18 @@ int rtiow_debug_read_rng(rtiow_handle h, uint32_t* host_states, size_t count_wor
     HIP_TRY(h, hipMemcpy(soa.data(), h->rng, npix * 6 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (size_t p = 0; p < npix; ++p)
         for (int k = 0; k < 6; ++k) host_states[p * 6 + k] = soa[k * npix + p];
+    return 0;
+}
+
+int rtiow_debug_read_costs(rtiow_handle h, uint32_t* own, uint32_t* smoothed, size_t count) {
+    if (!h || !own || !smoothed) return RTIOW_E_BADARG;
+    const size_t npix = (size_t)img_w(h) * h->local_rows;
+    if (h->stats.phases != 2 || !h->cost || !h->cost_rank) return fail_arg(h, RTIOW_E_STATE, "rtiow_debug_read_costs: the last render did not sort");
+    if (count < npix) return fail_arg(h, RTIOW_E_BADARG, "rtiow_debug_read_costs: buffer too small");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(own, h->cost, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(smoothed, h->cost_rank, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -731,6 +731,34 @@ def test_solo_waves_leave_the_image_alone(rt, oracle, prec, scene_id, W, H, S, B
             assert _same_bits(got[row:row + 1], want), row
 
 
+@pytest.mark.parametrize("W,H,shard", [(640, 360, None), (333, 217, None), (1920, 1080, (3, 8, 2)), (700, 300, (1, 3, 5))])
+def test_sort_key_is_the_neighbourhood_mean_of_the_prepass_cost(rt, W, H, shard):
+    """cost_smooth_kernel (LDS tiles) against the definition: the mean of the prepass cost over the 13 x 13 window
+    clipped to the image and to the pixel's own row strip, in quarter segments, rounded to nearest."""
+    with rt.Renderer(0, 32) as r:
+        r.set_camera(rt.camera(32, W, H, 32, 50)); r.set_scene(rt.build_scene(3, 32))
+        strip = H                                            # one rank: its strips are adjacent, the window crosses them
+        if shard:
+            r.set_shard(*shard); strip = shard[2]
+        r.init_rng(1227)
+        r.render(0)
+        assert r.stats()["phases"] == 2
+        own, smoothed = r.debug_read_costs()
+    rows = own.shape[0]
+    assert own.min() >= 2 and own.max() <= 2 * 50            # two prepass samples of 1..50 segments each
+    hw = 6
+    csum = np.zeros((rows + 1, W + 1), np.int64)
+    csum[1:, 1:] = own.astype(np.int64).cumsum(0).cumsum(1)
+    jl = np.arange(rows)[:, None]; i = np.arange(W)[None, :]
+    s0 = (jl // strip) * strip
+    j0 = np.maximum(jl - hw, s0); j1 = np.minimum(np.minimum(jl + hw, s0 + strip - 1), rows - 1)
+    i0 = np.maximum(i - hw, 0); i1 = np.minimum(i + hw, W - 1)
+    total = csum[j1 + 1, i1 + 1] - csum[j0, i1 + 1] - csum[j1 + 1, i0] + csum[j0, i0]
+    cells = (j1 - j0 + 1) * (i1 - i0 + 1)
+    want = (4 * total + cells // 2) // cells
+    assert np.array_equal(smoothed.astype(np.int64), want)
+
+
 def test_full_size_properties(rt, oracle):
     """BASELINE headline config (scene 3, 1920x1080, 100 spp, 50 bounces): too big for the
     oracle in full, so: (1) run-to-run determinism, (2) 8-way sharded == whole image,
