@@ -103,6 +103,24 @@ def test_ppm_writer_semantics(native, tmp_path, oracle):
         native.write_ppm(str(tmp_path / "no_such_dir" / "x.ppm"), np.zeros((1, 1, 3), np.float32))
 
 
+def test_ppm_writer_threaded_ranges_keep_the_text(native, tmp_path):
+    """Frames of 65536 pixels or more are formatted on several threads, range by range, from buffers sized for levels
+    0..255; a range that holds a NaN level ("-2147483648") is formatted again in the long form.  Same bytes as a
+    per-channel restatement."""
+    rng = np.random.default_rng(3)
+    for dt in (np.float32, np.float64):
+        img = rng.uniform(-0.2, 1.2, (301, 257, 3)).astype(dt)
+        img[0, 0, 0] = np.nan; img[17, 5, 1] = np.nan; img[300, 256, 2] = np.nan; img[150, :, :] = np.nan   # first, last and a whole row
+        with np.errstate(invalid="ignore"):
+            lv = (dt(256) * np.clip(img, dt(0), dt(0.999))).astype(np.float64)
+        lv = np.where(np.isnan(img), -2147483648, np.trunc(np.nan_to_num(lv))).astype(np.int64).reshape(-1, 3)
+        want = ("P3\n257 301\n255\n" + "".join("%d %d %d\n" % tuple(r) for r in lv)).encode()
+        assert native.format_ppm(img) == want
+        path = str(tmp_path / "big.ppm")
+        native.write_ppm(path, img)
+        assert open(path, "rb").read() == want
+
+
 def test_shard_rows_partition_and_place_rows(native):
     for H, n, strip in [(1080, 8, 8), (1080, 3, 8), (192, 2, 8), (50, 4, 8), (7, 3, 2), (5, 8, 8), (1080, 1, 8)]:
         seen = []
