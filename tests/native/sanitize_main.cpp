@@ -76,6 +76,22 @@ template <class T> static void renders_and_writers(int prec, const char* tmpdir)
         CHECK(rtiow_host_write_ppm_binary(p6.c_str(), prec, W, H, img.data()) == 0);
         CHECK(rtiow_host_write_ppm((std::string(tmpdir) + "/no/such/dir/x.ppm").c_str(), prec, W, H, img.data()) != 0);
     }
+    // the threaded writer (65536 pixels or more): ranges formatted concurrently from tight buffers, NaN levels in the
+    // first and the last range force the long form
+    for (int prec : {32, 64}) {
+        const int W = 311, H = 277;
+        std::vector<double> img64((size_t)W * H * 3);
+        std::vector<float> img32(img64.size());
+        for (size_t k = 0; k < img64.size(); ++k) { img64[k] = (double)((k * 2654435761u) % 1300u) / 1000.0 - 0.15; img32[k] = (float)img64[k]; }
+        img64[1] = img64[img64.size() - 2] = std::nan(""); img32[1] = img32[img32.size() - 2] = std::nanf("");
+        const void* data = prec == 32 ? (const void*)img32.data() : (const void*)img64.data();
+        size_t len = 0;
+        CHECK(rtiow_host_format_ppm(prec, W, H, data, nullptr, 0, &len) == 0);
+        std::vector<char> text(len);
+        CHECK(rtiow_host_format_ppm(prec, W, H, data, text.data(), text.size(), &len) == 0 && len == text.size());
+        CHECK(text.back() == '\n' && std::memcmp(text.data(), "P3\n311 277\n255\n", 15) == 0);
+        CHECK(rtiow_host_write_ppm((std::string(tmpdir) + "/threaded.ppm").c_str(), prec, W, H, data) == 0);
+    }
     // serial semantics (the CPU baseline path), small frame
     unsigned long long st[4];
     std::vector<char> p3(1 << 20);
