@@ -1508,9 +1508,14 @@ __device__ __forceinline__ int cost_bin(unsigned c) { return c < (unsigned)COST_
 // One workgroup smooths a 64 x 16 tile from LDS: the tile with its halo, then the horizontal window sums of every
 // row it needs, then the vertical sums (26 LDS reads per pixel instead of 169 cached global loads: 61 -> 20 us on
 // the full frame).  Integer sums: the same values in any order.
+// The histogram of the keys (what cost_hist_kernel counts for an unsmoothed key) rides along: one LDS histogram
+// per tile, one global atomic per non-empty bin.
 constexpr int SMOOTH_TW = 64, SMOOTH_TH = 16;
-__global__ void __launch_bounds__(256) cost_smooth_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ out, int W, int rows, int strip_rows, int hw) {
+__global__ void __launch_bounds__(256) cost_smooth_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ out, int W, int rows, int strip_rows, int hw,
+                                                          unsigned* __restrict__ hist) {
     extern __shared__ uint32_t smooth_lds[];
+    __shared__ unsigned tile_hist[COST_BINS];
+    for (int b = threadIdx.x; b < COST_BINS; b += blockDim.x) tile_hist[b] = 0;
     const int halo_w = SMOOTH_TW + 2 * hw, halo_h = SMOOTH_TH + 2 * hw;
     uint32_t* tile = smooth_lds;                       // [halo_h][halo_w], zero outside the image
     uint32_t* hsum = smooth_lds + halo_w * halo_h;     // [halo_h][SMOOTH_TW]
@@ -1544,8 +1549,12 @@ __global__ void __launch_bounds__(256) cost_smooth_kernel(const uint32_t* __rest
         // mean over the window actually covered, in quarter segments: the bins keep their resolution at the image
         // border and in two-row strips
         const unsigned cells = (unsigned)((j1 - j0 + 1) * (i1 - i0 + 1));
-        out[jl * W + i] = (4u * sum + cells / 2) / cells;
+        const unsigned key = (4u * sum + cells / 2) / cells;
+        out[jl * W + i] = key;
+        atomicAdd(&tile_hist[cost_bin(key)], 1u);
     }
+    __syncthreads();
+    for (int b = threadIdx.x; b < COST_BINS; b += blockDim.x) if (tile_hist[b]) atomicAdd(&hist[b], tile_hist[b]);
 }
 
 __global__ void __launch_bounds__(256) cost_hist_kernel(const uint32_t* __restrict__ cost, int npix, unsigned* __restrict__ hist) {
@@ -2294,10 +2303,11 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
 #ifdef RTIOW_TUNING
                 if (const char* e = std::getenv("RTIOW_TUNE_SMOOTH_STRIP")) window_strip = std::atoi(e) > 0 ? std::atoi(e) : (h->local_rows > 0 ? h->local_rows : 1);
 #endif
-                hipLaunchKernelGGL(cost_smooth_kernel, dim3(smooth_blocks), dim3(256), smooth_lds_bytes, h->stream, h->cost, h->cost_rank, p.cold.W, h->local_rows, window_strip, smooth_hw);
+                hipLaunchKernelGGL(cost_smooth_kernel, dim3(smooth_blocks), dim3(256), smooth_lds_bytes, h->stream, h->cost, h->cost_rank, p.cold.W, h->local_rows, window_strip, smooth_hw, hist);
                 rank_by = h->cost_rank;
+            } else {
+                hipLaunchKernelGGL(cost_hist_kernel, dim3(sort_blocks < 1024 ? sort_blocks : 1024), dim3(256), 0, h->stream, rank_by, npix, hist);
             }
-            hipLaunchKernelGGL(cost_hist_kernel, dim3(sort_blocks < 1024 ? sort_blocks : 1024), dim3(256), 0, h->stream, rank_by, npix, hist);
             hipLaunchKernelGGL(cost_scan_kernel, dim3(1), dim3(COST_BINS), 0, h->stream, hist, start, fill);
             const int resident_waves = (int)blocks * waves_per_block;
             const int age_classes = (int)((blocks + h->num_cus - 1) / h->num_cus);
