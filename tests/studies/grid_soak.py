@@ -1,6 +1,6 @@
 """Soak run for the grid walk (not a test; run by hand on a GPU box): many random scenes, each probed with adversarial
 rays through rtiow_debug_hit_world -- grid walk vs the exact loop, ray by ray.  Prints one line per scene and a
-summary; exits non-zero on the first mismatch.      python tests/studies/grid_soak.py [n_scenes] [rays_per_family]"""
+summary; exits non-zero on the first mismatch.      python tests/studies/grid_soak.py [n_scenes] [rays_per_family] [first_seed]"""
 import os
 import sys
 
@@ -14,9 +14,10 @@ from tests.test_grid_plan import _plan  # noqa: E402
 
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n_each = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
+first_seed = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
 used = rays_total = 0
 for seed in range(n_scenes):
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(first_seed + seed)
     prec = 32 if seed % 2 == 0 else 64
     n = int(rng.integers(40, 900))
     half = float(np.exp(rng.uniform(np.log(2), np.log(60))))
