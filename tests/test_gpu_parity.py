@@ -3,6 +3,7 @@ CPU oracle on the same seeded inputs.  The bar is BIT-EXACT: kernel and oracle s
 floating-point contract (IEEE + - * / sqrt, explicit fma placements, no other contraction;
 see DESIGN.md), so every pixel's float bits must agree, in fp32 and in fp64.
 """
+import json
 import os
 import re
 import subprocess
@@ -335,6 +336,17 @@ def test_benchmark_harness_csv_round_trip(rt, tmp_path):
     exe = os.path.join(os.path.dirname(rt.lib_paths()["hip"]), "..", "bin", "csv_avg")
     assert subprocess.run([exe, csv, avg], capture_output=True).returncode == 0
     assert len(open(avg).read().splitlines()) == 1 + 4
+    # the same loop with a JSON line per run next to the CSV, and the BASELINE.json preset
+    side = str(tmp_path / "stats.jsonl")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "hip_benchmark.sh"), "float", csv], env=dict(env, STATS_JSONL=side, RUNS="1"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = [json.loads(l) for l in open(side)]
+    assert len(rows) == 4 and all(row["stats"]["mrays_per_s"] > 0 and row["stats"]["wall_ms"]["end_to_end"] > 0 for row in rows)
+    assert [(row["width"], row["threads"]) for row in rows] == [(64, 8), (96, 8), (64, 16), (96, 16)]
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "hip_benchmark.sh"), "float", csv], env=dict(os.environ, BASELINE_CONFIGS="1", RUNS="1", STATS_JSONL=side), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert [l.split(",")[:5] for l in open(csv).read().splitlines()[1:]] == [["1", "320", "192", "10", "25"], ["3", "1280", "720", "100", "50"], ["3", "1920", "1080", "100", "50"]]
+    assert [json.loads(l)["stats"]["solo_waves"] for l in open(side)] == [0, 256, 0]
 
 
 def _custom(rt, prec, scene, W, H, S, B, source, sched=2):
