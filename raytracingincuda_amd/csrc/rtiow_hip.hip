@@ -52,9 +52,60 @@ struct Rng { uint32_t v0, v1, v2, v3, v4, d; };
 __device__ __forceinline__ uint32_t rng_next(Rng& s) {
     uint32_t t = s.v0 ^ (s.v0 >> 2);
     s.v0 = s.v1; s.v1 = s.v2; s.v2 = s.v3; s.v3 = s.v4;
-    s.v4 = (s.v4 ^ (s.v4 << 4)) ^ (t ^ (t << 1));
+    // gfx950's three-input bit operation (truth table 0x96 = a^b^c) takes one of the four xors: 6 instead
+    // of 7 vector instructions per draw (profiles/r02_ab_xorwow_bitop3.jsonl: -2.4 % SQ_INSTS_VALU, -1.2 % time)
+    s.v4 = __builtin_amdgcn_bitop3_b32(s.v4, s.v4 << 4, t, 0x96) ^ (t << 1);
     s.d += 362437u;
     return s.v4 + s.d;
+}
+
+// Two / three draws at once with the state rotated IN PLACE (fp32 rejection loops).  A loop whose round
+// draws k numbers rotates the five state words by k places per trip; the compiler materialises that as five
+// register copies at the back edge.  Tied operands leave nothing to copy at the back edge, and inside the block
+// a rotation by three takes two moves and one by two takes three: 20 instead of 23 vector instructions for
+// three draws, 15 instead of 17 for two.  Draw i of the block is then (new word) + d + i * 362437.
+__device__ __forceinline__ void rng_step3(Rng& s) {      // afterwards the draws are v2 + d1, v3 + d2, v4 + d3
+    uint32_t t1, t2, t3, c;
+    asm("v_lshrrev_b32 %5, 2, %0\n\t"
+        "v_lshrrev_b32 %6, 2, %1\n\t"
+        "v_lshrrev_b32 %7, 2, %2\n\t"
+        "v_xor_b32 %5, %5, %0\n\t"
+        "v_xor_b32 %6, %6, %1\n\t"
+        "v_xor_b32 %7, %7, %2\n\t"
+        "v_mov_b32 %0, %3\n\t"
+        "v_mov_b32 %1, %4\n\t"
+        "v_lshlrev_b32 %8, 4, %4\n\t"
+        "v_bitop3_b32 %2, %4, %8, %5 bitop3:0x96\n\t"
+        "v_lshlrev_b32 %5, 1, %5\n\t"
+        "v_xor_b32 %2, %2, %5\n\t"
+        "v_lshlrev_b32 %8, 4, %2\n\t"
+        "v_bitop3_b32 %3, %2, %8, %6 bitop3:0x96\n\t"
+        "v_lshlrev_b32 %6, 1, %6\n\t"
+        "v_xor_b32 %3, %3, %6\n\t"
+        "v_lshlrev_b32 %8, 4, %3\n\t"
+        "v_bitop3_b32 %4, %3, %8, %7 bitop3:0x96\n\t"
+        "v_lshlrev_b32 %7, 1, %7\n\t"
+        "v_xor_b32 %4, %4, %7"
+        : "+v"(s.v0), "+v"(s.v1), "+v"(s.v2), "+v"(s.v3), "+v"(s.v4), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(c));
+}
+__device__ __forceinline__ void rng_step2(Rng& s) {      // afterwards the draws are v3 + d1, v4 + d2
+    uint32_t t1, t2, c;
+    asm("v_lshrrev_b32 %5, 2, %0\n\t"
+        "v_lshrrev_b32 %6, 2, %1\n\t"
+        "v_xor_b32 %5, %5, %0\n\t"
+        "v_xor_b32 %6, %6, %1\n\t"
+        "v_mov_b32 %0, %2\n\t"
+        "v_mov_b32 %1, %3\n\t"
+        "v_lshlrev_b32 %7, 4, %4\n\t"
+        "v_bitop3_b32 %3, %4, %7, %5 bitop3:0x96\n\t"
+        "v_lshlrev_b32 %5, 1, %5\n\t"
+        "v_mov_b32 %2, %4\n\t"
+        "v_xor_b32 %3, %3, %5\n\t"
+        "v_lshlrev_b32 %7, 4, %3\n\t"
+        "v_bitop3_b32 %4, %3, %7, %6 bitop3:0x96\n\t"
+        "v_lshlrev_b32 %6, 1, %6\n\t"
+        "v_xor_b32 %4, %4, %6"
+        : "+v"(s.v0), "+v"(s.v1), "+v"(s.v2), "+v"(s.v3), "+v"(s.v4), "=&v"(t1), "=&v"(t2), "=&v"(c));
 }
 
 template <class T> struct Real;
@@ -66,6 +117,22 @@ template <> struct Real<float> {
     }
     static __device__ __forceinline__ float from_u32(uint32_t x) {
         return __builtin_fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+    }
+    static __device__ __forceinline__ void uniform2(Rng& s, float& a, float& b) {
+#ifdef RTIOW_NO_INPLACE_RNG
+        a = uniform(s); b = uniform(s);
+#else
+        rng_step2(s);
+        a = from_u32(s.v3 + (s.d + 362437u)); s.d += 2u * 362437u; b = from_u32(s.v4 + s.d);
+#endif
+    }
+    static __device__ __forceinline__ void uniform3(Rng& s, float& a, float& b, float& c) {
+#ifdef RTIOW_NO_INPLACE_RNG
+        a = uniform(s); b = uniform(s); c = uniform(s);
+#else
+        rng_step3(s);
+        a = from_u32(s.v2 + (s.d + 362437u)); b = from_u32(s.v3 + (s.d + 2u * 362437u)); s.d += 3u * 362437u; c = from_u32(s.v4 + s.d);
+#endif
     }
     static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
     static __device__ __forceinline__ float sqrt(float a) { return __builtin_sqrtf(a); }
@@ -86,6 +153,8 @@ template <> struct Real<double> {
     static __device__ __forceinline__ double from_u32(uint32_t x) {
         return __builtin_fma((double)x, 1.1102230246251565e-16, 5.5511151231257827e-17);
     }
+    static __device__ __forceinline__ void uniform2(Rng& s, double& a, double& b) { a = uniform(s); b = uniform(s); }
+    static __device__ __forceinline__ void uniform3(Rng& s, double& a, double& b, double& c) { a = uniform(s); b = uniform(s); c = uniform(s); }
     static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
     static __device__ __forceinline__ double sqrt(double a) { return __builtin_sqrt(a); }
     static __device__ __forceinline__ double fmin(double a, double b) { return __builtin_fmin(a, b); }
@@ -310,9 +379,11 @@ template <class T> __device__ __forceinline__ V3<T> random_unit_vector(Rng& s) {
     REGION_BEGIN(ruv);
     for (;;) {
         PATH_STAT(PS_RUV_ROUND);
-        x = RT_FMA(Real<T>::uniform(s), (T)2, (T)-1);
-        y = RT_FMA(Real<T>::uniform(s), (T)2, (T)-1);
-        z = RT_FMA(Real<T>::uniform(s), (T)2, (T)-1);
+        T u0, u1, u2;
+        Real<T>::uniform3(s, u0, u1, u2);
+        x = RT_FMA(u0, (T)2, (T)-1);
+        y = RT_FMA(u1, (T)2, (T)-1);
+        z = RT_FMA(u2, (T)2, (T)-1);
         lensq = RT_FMA(z, z, RT_FMA(y, y, x * x));
         if (Real<T>::ruv_eps < lensq && lensq <= (T)1) break;
 #ifdef RTIOW_ABLATE_RUV_ROUNDS
@@ -339,8 +410,10 @@ __device__ __forceinline__ void gen_primary(const RenderParams<T>& p, int i, int
         T px, py;
         for (;;) {
             PATH_STAT(PS_DISK_ROUND);
-            px = RT_FMA((T)2, Real<T>::uniform(s), (T)-1);
-            py = RT_FMA((T)2, Real<T>::uniform(s), (T)-1);
+            T u0, u1;
+            Real<T>::uniform2(s, u0, u1);
+            px = RT_FMA((T)2, u0, (T)-1);
+            py = RT_FMA((T)2, u1, (T)-1);
             if (RT_FMA(py, py, px * px) < (T)1) break;
 #ifdef RTIOW_ABLATE_DISK_ROUNDS
             break;

@@ -800,6 +800,32 @@ def test_full_size_properties(rt, oracle):
         assert _same_bits(a[row:row + 1], want), row
 
 
+def _full_frame_names():
+    from tests.golden.make_full_frame_crcs import CONFIGS
+    return [c[0] for c in CONFIGS]
+
+
+@pytest.mark.parametrize("name", _full_frame_names())
+def test_full_frames_match_the_oracle_row_by_row(rt, golden_dir, name):
+    """Every pixel of the BASELINE.json frames (configs[2], [3] = headline, [4], the fp64 headline and the
+    487-sphere scene at 1080p / at the reference grid's largest frame) against the oracle's full render of
+    the same frame: tests/golden/full_frame_crcs.json holds one CRC-32 per row of the raw float bits and the
+    SHA-256 of the image (tests/golden/make_full_frame_crcs.py, minutes of CPU per frame).  Default
+    schedule and scene source, i.e. exactly what bench.py and the executables run."""
+    import hashlib
+    import zlib
+    gold = json.load(open(os.path.join(golden_dir, "full_frame_crcs.json")))
+    if name not in gold:
+        pytest.skip("no golden for %s yet (tests/golden/make_full_frame_crcs.py %s)" % (name, name))
+    g = gold[name]
+    img = _render(rt, g["precision"], g["scene_id"], g["width"], g["height"], g["samples"], g["bounces"], threads=0, seed=g["seed"])
+    assert img.shape == (g["height"], g["width"], 3) and img.dtype == (np.float32 if g["precision"] == 32 else np.float64)
+    crcs = [zlib.crc32(np.ascontiguousarray(img[j]).view(np.uint8).tobytes()) & 0xffffffff for j in range(img.shape[0])]
+    bad = [j for j in range(img.shape[0]) if crcs[j] != g["row_crc32"][j]]
+    assert not bad, "%s: %d rows differ from the oracle, first %s" % (name, len(bad), bad[:8])
+    assert hashlib.sha256(np.ascontiguousarray(img).view(np.uint8).tobytes()).hexdigest() == g["sha256"]
+
+
 def test_bench_prints_one_contract_line(rt):
     """bench.py's contract with the driver: exactly one JSON line on stdout with the agreed fields,
     the roofline of the dominant launch and the CPU baseline (small frame so the CPU leg takes a second)."""

@@ -444,3 +444,26 @@ def test_sky_comes_from_the_primary_ray_mirror_known_answer(oracle, native, prec
     # |d sky / d uy| <= 0.25 per unit of uy; a pixel is |dv|/10 of uy, the lens 0.052/10
     slack = 0.25 * (np.linalg.norm(dv) + np.linalg.norm(du) + 0.06) / 10.0
     assert np.abs(empty.astype(np.float64) ** 2 - want).max() <= slack
+
+
+def test_full_frame_goldens_are_what_the_oracle_renders(oracle, native, golden_dir):
+    """tests/golden/full_frame_crcs.json (the -m gpu full-frame parity test compares the HIP path with it) is the
+    oracle's output: structure, and three whole rows of every frame re-rendered here (sky / glass band / ground)."""
+    import zlib
+    from tests.conftest import compact
+    from tests.golden.make_full_frame_crcs import CONFIGS
+    gold = json.load(open(os.path.join(golden_dir, "full_frame_crcs.json")))
+    assert set(gold) <= {c[0] for c in CONFIGS} and len(gold) >= 3
+    for name, prec, scene_id, W, H, S, B in CONFIGS:
+        if name not in gold:
+            continue
+        g = gold[name]
+        assert (g["precision"], g["scene_id"], g["width"], g["height"], g["samples"], g["bounces"], g["seed"]) == (prec, scene_id, W, H, S, B, 1227)
+        assert len(g["row_crc32"]) == H and len(g["sha256"]) == 64 and g["oracle_stats"][0] == W * H * S
+        if S > 100:
+            continue                                           # the 500 spp frame: structure only (a row is 1e6 rays)
+        scene = compact(oracle.build_scene(scene_id, prec))
+        cam = native.camera(prec, W, H, S, B)
+        for row in (3, (H * 57) // 100, H - 2):
+            img, _ = oracle.render(prec, scene, cam, 1227, row, row + 1)
+            assert zlib.crc32(img.view(np.uint8).tobytes()) & 0xffffffff == g["row_crc32"][row], (name, row)
