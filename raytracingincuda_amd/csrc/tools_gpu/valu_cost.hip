@@ -63,7 +63,13 @@ constexpr int UNROLL = 16;
     X(46, v_fma_f32_neg,    "v_fma_f32 %0, -%2, %3, %0",                         1) \
     X(47, v_mad_u32_u24,    "v_mad_u32_u24 %0, %0, 16, %2",                      1) \
     X(48, v_bfe_u32,        "v_bfe_u32 %0, %0, 2, 30",                           1) \
-    X(49, v_alignbit_b32,   "v_alignbit_b32 %0, %2, %0, 2",                      1)
+    X(49, v_alignbit_b32,   "v_alignbit_b32 %0, %2, %0, 2",                      1) \
+    X(50, cmp_then_3_cndmask, "v_cmp_lt_f32_e32 vcc, %2, %0\n\tv_cndmask_b32_e32 %0, %2, %0, vcc\n\tv_cndmask_b32_e32 %0, %3, %0, vcc\n\tv_cndmask_b32_e32 %0, %2, %0, vcc", 4) \
+    X(51, v_cndmask_e64_vcc, "v_cndmask_b32_e64 %0, %2, %0, vcc",                1) \
+    X(52, salu_vcc_then_cndmask, "s_mov_b64 vcc, s[22:23]\n\ts_nop 4\n\tv_cndmask_b32_e32 %0, %2, %0, vcc", 1) \
+    X(53, cmp_e64_then_cndmask_e64, "v_cmp_lt_f32_e64 s[22:23], %2, %0\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, %2, %0, s[22:23]", 2) \
+    X(54, v_bitop3_b32,     "v_bitop3_b32 %0, %2, %0, %3 bitop3:0x96",           1) \
+    X(55, v_cndmask_same_src, "v_cndmask_b32_e32 %0, %0, %0, vcc",                1)
 
 template <int KIND>
 __global__ void __launch_bounds__(256) cost_kernel(float* out, float seed, f2 sg) {
