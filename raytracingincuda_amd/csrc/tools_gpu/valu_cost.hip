@@ -69,7 +69,15 @@ constexpr int UNROLL = 16;
     X(52, salu_vcc_then_cndmask, "s_mov_b64 vcc, s[22:23]\n\ts_nop 4\n\tv_cndmask_b32_e32 %0, %2, %0, vcc", 1) \
     X(53, cmp_e64_then_cndmask_e64, "v_cmp_lt_f32_e64 s[22:23], %2, %0\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, %2, %0, s[22:23]", 2) \
     X(54, v_bitop3_b32,     "v_bitop3_b32 %0, %2, %0, %3 bitop3:0x96",           1) \
-    X(55, v_cndmask_same_src, "v_cndmask_b32_e32 %0, %0, %0, vcc",                1)
+    X(55, v_cndmask_same_src, "v_cndmask_b32_e32 %0, %0, %0, vcc",                1) \
+    X(56, cmp_nop_cndmask_e32, "v_cmp_lt_f32_e32 vcc, %2, %0\n\ts_nop 1\n\tv_cndmask_b32_e32 %0, %2, %0, vcc", 2) \
+    X(57, cmp_nop_cndmask_e64, "v_cmp_lt_f32_e32 vcc, %2, %0\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, %2, %0, vcc", 2) \
+    X(58, cmp_nop_3_cndmask_e32, "v_cmp_lt_f32_e32 vcc, %2, %0\n\ts_nop 1\n\tv_cndmask_b32_e32 %0, %2, %0, vcc\n\tv_cndmask_b32_e32 %0, %3, %0, vcc\n\tv_cndmask_b32_e32 %0, %2, %0, vcc", 4) \
+    X(59, cmp_nop_3_cndmask_e64, "v_cmp_lt_f32_e32 vcc, %2, %0\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, %2, %0, vcc\n\tv_cndmask_b32_e64 %0, %3, %0, vcc\n\tv_cndmask_b32_e64 %0, %2, %0, vcc", 4) \
+    X(60, cmp_2xor_cndmask_e32, "v_cmp_lt_f32_e32 vcc, %2, %0\n\tv_xor_b32_e32 %0, %3, %0\n\tv_xor_b32_e32 %0, %2, %0\n\tv_cndmask_b32_e32 %0, %2, %0, vcc", 4) \
+    X(61, cmp_2xor_cndmask_e64, "v_cmp_lt_f32_e32 vcc, %2, %0\n\tv_xor_b32_e32 %0, %3, %0\n\tv_xor_b32_e32 %0, %2, %0\n\tv_cndmask_b32_e64 %0, %2, %0, vcc", 4) \
+    X(62, cmp_e32_alone_nop,  "v_cmp_lt_f32_e32 vcc, %2, %0\n\ts_nop 1\n\tv_xor_b32_e32 %0, %3, %0", 2) \
+    X(63, v_add_u32_self,     "v_add_u32_e32 %0, %0, %0",                          1)
 
 template <int KIND>
 __global__ void __launch_bounds__(256) cost_kernel(float* out, float seed, f2 sg) {
