@@ -54,7 +54,11 @@ __device__ __forceinline__ uint32_t rng_next(Rng& s) {
     s.v0 = s.v1; s.v1 = s.v2; s.v2 = s.v3; s.v3 = s.v4;
     // gfx950's three-input bit operation (truth table 0x96 = a^b^c) takes one of the four xors: 6 instead
     // of 7 vector instructions per draw (profiles/r02_ab_xorwow_bitop3.jsonl: -2.4 % SQ_INSTS_VALU, -1.2 % time)
-    s.v4 = __builtin_amdgcn_bitop3_b32(s.v4, s.v4 << 4, t, 0x96) ^ (t << 1);
+    // t << 1 as t + t: on gfx950 v_lshlrev_b32 issues at 5.3 cycles per wave-instruction, v_add_u32 at 3.7
+    // (bin/valu_cost); the compiler turns a source-level t + t back into the shift, hence the one-line asm.
+    uint32_t t2;
+    asm("v_add_u32 %0, %1, %1" : "=v"(t2) : "v"(t));
+    s.v4 = __builtin_amdgcn_bitop3_b32(s.v4, s.v4 << 4, t, 0x96) ^ t2;
     s.d += 362437u;
     return s.v4 + s.d;
 }
@@ -64,6 +68,7 @@ __device__ __forceinline__ uint32_t rng_next(Rng& s) {
 // register copies at the back edge.  Tied operands leave nothing to copy at the back edge, and inside the block
 // a rotation by three takes two moves and one by two takes three: 20 instead of 23 vector instructions for
 // three draws, 15 instead of 17 for two.  Draw i of the block is then (new word) + d + i * 362437.
+// (t << 1 is written t + t: v_add_u32 issues faster than v_lshlrev_b32, see rng_next.)
 __device__ __forceinline__ void rng_step3(Rng& s) {      // afterwards the draws are v2 + d1, v3 + d2, v4 + d3
     uint32_t t1, t2, t3, c;
     asm("v_lshrrev_b32 %5, 2, %0\n\t"
@@ -76,15 +81,15 @@ __device__ __forceinline__ void rng_step3(Rng& s) {      // afterwards the draws
         "v_mov_b32 %1, %4\n\t"
         "v_lshlrev_b32 %8, 4, %4\n\t"
         "v_bitop3_b32 %2, %4, %8, %5 bitop3:0x96\n\t"
-        "v_lshlrev_b32 %5, 1, %5\n\t"
+        "v_add_u32 %5, %5, %5\n\t"
         "v_xor_b32 %2, %2, %5\n\t"
         "v_lshlrev_b32 %8, 4, %2\n\t"
         "v_bitop3_b32 %3, %2, %8, %6 bitop3:0x96\n\t"
-        "v_lshlrev_b32 %6, 1, %6\n\t"
+        "v_add_u32 %6, %6, %6\n\t"
         "v_xor_b32 %3, %3, %6\n\t"
         "v_lshlrev_b32 %8, 4, %3\n\t"
         "v_bitop3_b32 %4, %3, %8, %7 bitop3:0x96\n\t"
-        "v_lshlrev_b32 %7, 1, %7\n\t"
+        "v_add_u32 %7, %7, %7\n\t"
         "v_xor_b32 %4, %4, %7"
         : "+v"(s.v0), "+v"(s.v1), "+v"(s.v2), "+v"(s.v3), "+v"(s.v4), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(c));
 }
@@ -98,12 +103,12 @@ __device__ __forceinline__ void rng_step2(Rng& s) {      // afterwards the draws
         "v_mov_b32 %1, %3\n\t"
         "v_lshlrev_b32 %7, 4, %4\n\t"
         "v_bitop3_b32 %3, %4, %7, %5 bitop3:0x96\n\t"
-        "v_lshlrev_b32 %5, 1, %5\n\t"
+        "v_add_u32 %5, %5, %5\n\t"
         "v_mov_b32 %2, %4\n\t"
         "v_xor_b32 %3, %3, %5\n\t"
         "v_lshlrev_b32 %7, 4, %3\n\t"
         "v_bitop3_b32 %4, %3, %7, %6 bitop3:0x96\n\t"
-        "v_lshlrev_b32 %6, 1, %6\n\t"
+        "v_add_u32 %6, %6, %6\n\t"
         "v_xor_b32 %4, %4, %6"
         : "+v"(s.v0), "+v"(s.v1), "+v"(s.v2), "+v"(s.v3), "+v"(s.v4), "=&v"(t1), "=&v"(t2), "=&v"(c));
 }
