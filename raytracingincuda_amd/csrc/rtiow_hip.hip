@@ -375,6 +375,33 @@ __device__ __forceinline__ void region_add(int region, unsigned long long t0) {
 #define REGION_END(name, region) ((void)0)
 #endif
 
+// 1 / sqrt(lensq) of an ACCEPTED candidate (vec3.h:126: p / sqrt(lensq)), i.e. the IEEE square root followed by the
+// IEEE reciprocal, for an operand known to lie in (1e-8, 1].  The compiler's correctly rounded sequences (15 + 11
+// instructions) spend 10 of them on what such an operand never needs: the 2^32 pre-scaling of a square root below
+// 2^-96 with its un-scaling, the zero / infinity pass-through, v_div_scale on both operands (no scaling for a
+// numerator 1 and a denominator in [1e-4, 1]: the scaled values ARE the operands and the flag is clear, so
+// v_div_fmas is a plain fma) and v_div_fixup (specials only).  What is left is those sequences' own arithmetic,
+// instruction for instruction: raw v_sqrt_f32 (<= 1 ulp) corrected by the two residual tests against its neighbours,
+// then raw v_rcp_f32 with one Newton step and the two quotient refinements.  Same bits as
+// `1.0f / sqrtf(lensq)` (the full-frame goldens compare every pixel); fp64 keeps the generic code.
+__device__ __forceinline__ float inv_sqrt_accepted(float x) {
+#ifdef RTIOW_GENERIC_RUV_NORMALISATION
+    return 1.0f / __builtin_sqrtf(x);
+#else
+    const float s0 = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s0) - 1u), sp = __uint_as_float(__float_as_uint(s0) + 1u);
+    const float rm = __builtin_fmaf(-sm, s0, x), rp = __builtin_fmaf(-sp, s0, x);
+    float s = rm <= 0.0f ? sm : s0;
+    s = rp > 0.0f ? sp : s;
+    float r = __builtin_amdgcn_rcpf(s);
+    r = __builtin_fmaf(__builtin_fmaf(-s, r, 1.0f), r, r);
+    float q = r;                                             // numerator 1: q = 1 * r
+    q = __builtin_fmaf(__builtin_fmaf(-s, q, 1.0f), r, q);
+    return __builtin_fmaf(__builtin_fmaf(-s, q, 1.0f), r, q);
+#endif
+}
+__device__ __forceinline__ double inv_sqrt_accepted(double x) { return 1.0 / __builtin_sqrt(x); }
+
 template <class T> __device__ __forceinline__ V3<T> random_unit_vector(Rng& s) {   // vec3.h:117-127
     // The rejection loop only finds the accepted candidate; its normalisation (an IEEE sqrt and
     // divide, ~30 instructions) runs once after the loop instead of in every round the wave
@@ -396,7 +423,7 @@ template <class T> __device__ __forceinline__ V3<T> random_unit_vector(Rng& s) {
 #endif
     }
     REGION_END(ruv, RG_RUV_ROUNDS);
-    const T inv = (T)1 / Real<T>::sqrt(lensq);
+    const T inv = inv_sqrt_accepted(lensq);
     return {inv * x, inv * y, inv * z};
 }
 
