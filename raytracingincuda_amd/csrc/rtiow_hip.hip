@@ -33,6 +33,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <array>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -274,6 +275,7 @@ template <class T> struct ColdParams {
 template <class T> struct RenderParams {
     int B, s_end;                     // bounce limit; this launch renders samples [cold.s_begin, s_end)
     int lane_cap;                     // lanes of a wave that take pixels (64; fewer when the launch is underfilled, see launch_render)
+    int primary_len_in_range;         // host-checked (primary_rays_in_range): |D|^2 of every primary ray lies well inside [2^-80, 2^80]
     V3<T> center, pixel00, du, dv;
     T defocus_angle;
     V3<T> ddu, ddv;
@@ -384,6 +386,9 @@ __device__ __forceinline__ void region_add(int region, unsigned long long t0) {
 // instruction for instruction: raw v_sqrt_f32 (<= 1 ulp) corrected by the two residual tests against its neighbours,
 // then raw v_rcp_f32 with one Newton step and the two quotient refinements.  Same bits as
 // `1.0f / sqrtf(lensq)` (the full-frame goldens compare every pixel); fp64 keeps the generic code.
+// The same holds for any operand in [2^-80, 2^80] (square root in [2^-40, 2^40]: v_sqrt_f32 needs no scaling
+// from 2^-96 up, v_div_scale none while the exponents of 1 and the root differ by less than 96): gen_primary
+// uses it for |D|^2 of the primary rays when the host has bounded that for the whole frame.
 __device__ __forceinline__ float inv_sqrt_accepted(float x) {
 #ifdef RTIOW_GENERIC_RUV_NORMALISATION
     return 1.0f / __builtin_sqrtf(x);
@@ -455,7 +460,10 @@ __device__ __forceinline__ void gen_primary(const RenderParams<T>& p, int i, int
     }
     O = org;
     D = {ps.x - org.x, ps.y - org.y, ps.z - org.z};
-    T inv = (T)1 / Real<T>::sqrt(dot3(D, D));
+    const T dd = dot3(D, D);
+    T inv;
+    if (sizeof(T) == 4 && p.primary_len_in_range) inv = inv_sqrt_accepted(dd);   // wave-uniform choice, same bits
+    else inv = (T)1 / Real<T>::sqrt(dd);
     sky_uy = inv * D.y;
 }
 
@@ -1902,9 +1910,35 @@ int ensure_framebuffer(rtiow_handle_s* h) {
     return 0;
 }
 
+// Can gen_primary take 1/sqrt(|D|^2) without range handling (inv_sqrt_accepted)?  D = pixel sample - lens point:
+// the samples lie in the pixel plane (pixel00 + fi du + fj dv, fi in [-0.5, W - 0.5]), the lens points on the
+// defocus disk around the centre (|px|, |py| <= 1).  |D| is at most the sum of the extents and at least the
+// distance of the lens from the pixel plane; both with room for the fp32 rounding of coordinates up to M.
+template <class CAM>
+int primary_rays_in_range(const CAM& c) {
+    auto v = [](const auto* a) { return std::array<double, 3>{(double)a[0], (double)a[1], (double)a[2]}; };
+    auto dot = [](const std::array<double, 3>& a, const std::array<double, 3>& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    auto len = [&](const std::array<double, 3>& a) { return std::sqrt(dot(a, a)); };
+    const auto ctr = v(c.center), p00 = v(c.pixel00_loc), du = v(c.pixel_delta_u), dv = v(c.pixel_delta_v);
+    std::array<double, 3> ddu = v(c.defocus_disk_u), ddv = v(c.defocus_disk_v);
+    if (c.defocus_angle <= 0) ddu = ddv = {0, 0, 0};
+    const std::array<double, 3> rel = {p00[0] - ctr[0], p00[1] - ctr[1], p00[2] - ctr[2]};
+    std::array<double, 3> n = {du[1] * dv[2] - du[2] * dv[1], du[2] * dv[0] - du[0] * dv[2], du[0] * dv[1] - du[1] * dv[0]};
+    const double nl = len(n);
+    if (!(nl > 0) || !std::isfinite(nl)) return 0;
+    n = {n[0] / nl, n[1] / nl, n[2] / nl};
+    const double W = c.img_width + 1.0, H = c.img_height + 1.0;
+    const double dmax = len(rel) + W * len(du) + H * len(dv) + len(ddu) + len(ddv);
+    const double dmin = std::fabs(dot(rel, n)) - std::fabs(dot(ddu, n)) - std::fabs(dot(ddv, n));
+    const double M = len(ctr) + len(p00) + W * len(du) + H * len(dv) + len(ddu) + len(ddv);   // largest coordinate in play
+    const double slack = M * 0x1p-18;                                                          // >> the fp32 rounding of ps, org and D
+    return std::isfinite(dmax) && dmax + slack < 0x1p30 && dmin - slack > 0x1p-30;
+}
+
 template <class T, class CAM>
 RenderParams<T> make_params(const rtiow_handle_s* h, const CAM& c) {
     RenderParams<T> p;
+    p.primary_len_in_range = primary_rays_in_range(c);
     p.cold.W = c.img_width; p.cold.H = c.img_height; p.cold.S = c.samples_per_pixel; p.B = c.max_depth;
     p.cold.pixel_samples_scale = c.pixel_samples_scale;
     p.center = {c.center[0], c.center[1], c.center[2]};

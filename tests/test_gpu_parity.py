@@ -525,6 +525,21 @@ def test_grid_walk_on_degenerate_rays(rt, oracle, prec):
         assert _same_bits(a, b), (center, direction, "spread")
 
 
+def test_primary_ray_normalisation_paths_match_the_oracle(rt, oracle):
+    """gen_primary takes 1/sqrt(|D|^2) through the short in-range sequence when the host can bound |D| for the
+    whole frame (primary_rays_in_range) and through the compiler's full IEEE sequence otherwise.  The same view
+    with the pixel plane 2^-35 ... 2^35 away from the lens (the rays are the same lines; |D|^2 runs from 2^-70 to
+    2^70 and out of the range the host accepts at both ends) must give the oracle's bits on either path."""
+    sc = rt.build_scene(3, 32)
+    W, H, S, B = 48, 24, 3, 8
+    for log2_len in (-35, -25, -8, 0, 9, 25, 35):
+        cam = _crafted_camera(rt, 32, W, H, S, B, (13.0, 2.0, 3.0), tuple(np.array([-13.0, -2.0, -3.0]) / 13.49 * 2.0 ** log2_len),
+                              spread=2.0 ** log2_len * 0.01)
+        a, _ = _render_cam(rt, 32, sc, cam, rt.SCENE_GRID)
+        want, _ = oracle.render(32, compact(sc), cam, 1227)
+        assert _same_bits(a, want), log2_len
+
+
 def _adversarial_rays(rng, cr, plan, n_each):
     """Ray families a render rarely or never produces, around the grid of `plan` (tests/test_grid_plan._plan)."""
     x0, z0, cell, nx, nz = plan["x0"], plan["z0"], plan["cell"], plan["nx"], plan["nz"]
