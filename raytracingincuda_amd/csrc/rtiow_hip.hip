@@ -275,7 +275,8 @@ template <class T> struct ColdParams {
 template <class T> struct RenderParams {
     int B, s_end;                     // bounce limit; this launch renders samples [cold.s_begin, s_end)
     int lane_cap;                     // lanes of a wave that take pixels (64; fewer when the launch is underfilled, see launch_render)
-    int primary_len_in_range;         // host-checked (primary_rays_in_range): |D|^2 of every primary ray lies well inside [2^-80, 2^80]
+    int range_flags;                  // host-checked operand ranges.  bit 0 (primary_rays_in_range): |D|^2 of every primary ray lies well
+                                      // inside [2^-80, 2^80]; bit 1 (scene_in_range): every coordinate of spheres and lens is below 2^18
     V3<T> center, pixel00, du, dv;
     T defocus_angle;
     V3<T> ddu, ddv;
@@ -462,7 +463,7 @@ __device__ __forceinline__ void gen_primary(const RenderParams<T>& p, int i, int
     D = {ps.x - org.x, ps.y - org.y, ps.z - org.z};
     const T dd = dot3(D, D);
     T inv;
-    if (sizeof(T) == 4 && p.primary_len_in_range) inv = inv_sqrt_accepted(dd);   // wave-uniform choice, same bits
+    if (sizeof(T) == 4 && (p.range_flags & 1)) inv = inv_sqrt_accepted(dd);   // wave-uniform choice, same bits
     else inv = (T)1 / Real<T>::sqrt(dd);
     sky_uy = inv * D.y;
 }
@@ -503,23 +504,43 @@ __device__ __forceinline__ bool root_pretest_rejects(T h, T disc, T a, T closest
     return (int)((h + sq_approx) + e < behind_bound) | (int)((h - sq_approx) - e > far_bound);   // one branch, not two
 }
 
-template <class T, bool ANYORDER = false>
-__device__ __forceinline__ void ieee_roots(int s, T h, T disc, T a, T& closest, int& hit);
+// All roots of one ray are divided by the same a = d.d.  The correctly rounded fp32 division the compiler emits
+// is   d' = div_scale(a), n' = div_scale(n);  r = rcp(d'); r = fma(fma(-d', r, 1), r, r);        <- a only
+//      q = n' r; q = fma(fma(-d', q, n'), r, q); q = div_fmas(fma(-d', q, n'), r, q); div_fixup   <- per quotient
+// and for operands that need no scaling (d' = a, n' = n, flag clear: div_fmas is an fma, div_fixup the identity)
+// its first line depends on the ray alone.  hit_world_grid computes r once per segment (make_fast_div) and every
+// quotient of the segment is the second line's five instructions instead of eleven -- the same instructions on the
+// same values, hence the same bits.  "No scaling" is guaranteed, not tested per quotient: v_div_scale_f32 leaves
+// its operands alone while a is normal, 1/a is normal and -126 < exponent(n) - exponent(a) < 96.  The host vouches
+// for the scene (range_flags bit 1: every coordinate of spheres and lens below 2^18, so |oc| < 2^21), the wave
+// checks a in [2^-40, 2^40] for all its lanes (else the whole wave divides the long way for that segment), which
+// bounds |n| = |h -+ sqrt(disc)| by 2^43 and the exponent difference by 83.  A quotient so small that the IEEE
+// sequence would scale it is < 2^-80 on both paths and fails `tmin < root` either way; only accepted roots are stored.
+template <class T> struct FastDiv { T ra; bool on; };          // on is wave-uniform
+__device__ __forceinline__ float shared_rcp_quotient(float n, float a, float ra) {
+    float q = n * ra;
+    q = __builtin_fmaf(__builtin_fmaf(-a, q, n), ra, q);
+    return __builtin_fmaf(__builtin_fmaf(-a, q, n), ra, q);
+}
+__device__ __forceinline__ double shared_rcp_quotient(double n, double a, double) { return n / a; }   // never selected (fp64 keeps n / a)
 
 template <class T, bool ANYORDER = false>
-__device__ __forceinline__ void finish_sphere_test(int s, T h, T disc, T a, T& closest, int& hit) {
+__device__ __forceinline__ void ieee_roots(int s, T h, T disc, T a, T& closest, int& hit, FastDiv<T> fd);
+
+template <class T, bool ANYORDER = false>
+__device__ __forceinline__ void finish_sphere_test(int s, T h, T disc, T a, T& closest, int& hit, FastDiv<T> fd = FastDiv<T>{(T)0, false}) {
     PATH_STAT(PS_FINISH_CALL);
     if (root_pretest_rejects<T>(h, disc, a, closest)) return;
-    ieee_roots<T, ANYORDER>(s, h, disc, a, closest, hit);
+    ieee_roots<T, ANYORDER>(s, h, disc, a, closest, hit, fd);
 }
 
 // hittable.h:50-57 proper.
 template <class T, bool ANYORDER>
-__device__ __forceinline__ void ieee_roots(int s, T h, T disc, T a, T& closest, int& hit) {
+__device__ __forceinline__ void ieee_roots(int s, T h, T disc, T a, T& closest, int& hit, FastDiv<T> fd) {
     const T tmin = (T)0.001;
     PATH_STAT(PS_IEEE_BLOCK);
     const T sq = Real<T>::sqrt(disc);                               // :50
-    T root = (h - sq) / a;                                          // :53
+    T root = fd.on ? shared_rcp_quotient(h - sq, a, fd.ra) : (h - sq) / a;   // :53
     auto inside = [&](T r) {
         if (ANYORDER) return (tmin < r) && (r < closest || (r == closest && (unsigned)s < (unsigned)hit));
         return (tmin < r) && (r < closest);
@@ -527,7 +548,7 @@ __device__ __forceinline__ void ieee_roots(int s, T h, T disc, T a, T& closest, 
     bool ok = inside(root);                                         // :54
     if (!ok) {
         PATH_STAT(PS_SECOND_DIV);
-        root = (h + sq) / a;                                        // :55
+        root = fd.on ? shared_rcp_quotient(h + sq, a, fd.ra) : (h + sq) / a;   // :55
         ok = inside(root);                                          // :56
     }
     if (ok) { closest = root; hit = s; }                            // hittable.h:88-92
@@ -756,13 +777,13 @@ __device__ __forceinline__ void hit_world_screened(const RenderParams<T>& p, con
 // on random scenes (tests/test_gpu_parity.py).
 // =====================================================================================
 template <class T>
-__device__ __forceinline__ void direct_trip(const T* g, const int* ids, int s, const LoopRay<T>& r, T& closest, int& hit) {
+__device__ __forceinline__ void direct_trip(const T* g, const int* ids, int s, const LoopRay<T>& r, T& closest, int& hit, FastDiv<T> fd) {
     const Trip<T> t = trip_discriminants(g, s, r);
     // no common guard: some lane has a candidate on the direct list (the ground) in nearly every trip
-    if (t.d0 >= (T)0) finish_sphere_test<T, true>(ids[s + 0], t.h0, t.d0, r.a, closest, hit);
-    if (t.d1 >= (T)0) finish_sphere_test<T, true>(ids[s + 1], t.h1, t.d1, r.a, closest, hit);
-    if (t.d2 >= (T)0) finish_sphere_test<T, true>(ids[s + 2], t.h2, t.d2, r.a, closest, hit);
-    if (t.d3 >= (T)0) finish_sphere_test<T, true>(ids[s + 3], t.h3, t.d3, r.a, closest, hit);
+    if (t.d0 >= (T)0) finish_sphere_test<T, true>(ids[s + 0], t.h0, t.d0, r.a, closest, hit, fd);
+    if (t.d1 >= (T)0) finish_sphere_test<T, true>(ids[s + 1], t.h1, t.d1, r.a, closest, hit, fd);
+    if (t.d2 >= (T)0) finish_sphere_test<T, true>(ids[s + 2], t.h2, t.d2, r.a, closest, hit, fd);
+    if (t.d3 >= (T)0) finish_sphere_test<T, true>(ids[s + 3], t.h3, t.d3, r.a, closest, hit, fd);
 }
 
 // {cx, cy, cz, r*r} of sphere i for the per-lane gathers of the walk: fp32 from the AoS copy in the
@@ -779,7 +800,7 @@ __device__ __forceinline__ void load_sphere(const double* aos, int i, double& cx
 
 // The (up to) four spheres of one cell, hittable.h:42-57 each, for this lane's own ray.
 template <class T>
-__device__ __forceinline__ void cell_tests(const T* aos, unsigned rec_lo, unsigned rec_hi, V3<T> O, V3<T> D, T a, T& closest, int& hit) {
+__device__ __forceinline__ void cell_tests(const T* aos, unsigned rec_lo, unsigned rec_hi, V3<T> O, V3<T> D, T a, T& closest, int& hit, FastDiv<T> fd) {
     const int id[4] = {(int)(rec_lo & 0xffffu), (int)(rec_lo >> 16), (int)(rec_hi & 0xffffu), (int)(rec_hi >> 16)};
     T h[4], disc[4];
 #pragma unroll
@@ -796,7 +817,7 @@ __device__ __forceinline__ void cell_tests(const T* aos, unsigned rec_lo, unsign
         PATH_STAT(PS_EXACT_BLOCK);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (disc[k] >= (T)0) finish_sphere_test<T, true>(id[k], h[k], disc[k], a, closest, hit);
+            if (disc[k] >= (T)0) finish_sphere_test<T, true>(id[k], h[k], disc[k], a, closest, hit, fd);
     }
 }
 
@@ -859,17 +880,24 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
         const T* dg = reinterpret_cast<const T*>(smem_raw + g.direct_offset);
         const int* ids = reinterpret_cast<const int*>(smem_raw + g.direct_ids_offset);
         const LoopRay<T> r = make_loop_ray(o2.x, o2.y, o2.z, d2.x, d2.y, d2.z, a);
-        for (int s = 0; s < g.n_direct_padded; s += 4) direct_trip<T>(dg, ids, s, r, c2, h2);
+        for (int s = 0; s < g.n_direct_padded; s += 4) direct_trip<T>(dg, ids, s, r, c2, h2, FastDiv<T>{(T)0, false});
         RT_KEEP1(c2); RT_KEEP1(h2);
     }
 #endif
+    // ---- one reciprocal for every quotient of this segment (FastDiv above ieee_roots)
+    FastDiv<T> fd = {(T)0, false};
+    if (sizeof(T) == 4 && (p.range_flags & 2)) {
+        fd.on = __builtin_amdgcn_ballot_w64(!(af >= 0x1p-40f && af <= 0x1p40f)) == 0;
+        float r0 = __builtin_amdgcn_rcpf(af);
+        fd.ra = (T)__builtin_fmaf(__builtin_fmaf(-af, r0, 1.0f), r0, r0);
+    }
     // ---- the direct list: packed trips, every ray
     {
         const T* dg = reinterpret_cast<const T*>(smem_raw + g.direct_offset);
         const int* ids = reinterpret_cast<const int*>(smem_raw + g.direct_ids_offset);
         const LoopRay<T> r = make_loop_ray(O.x, O.y, O.z, D.x, D.y, D.z, a);
 #ifndef RTIOW_ABLATE_DIRECT
-        for (int s = 0; s < g.n_direct_padded; s += 4) direct_trip<T>(dg, ids, s, r, closest, hit);
+        for (int s = 0; s < g.n_direct_padded; s += 4) direct_trip<T>(dg, ids, s, r, closest, hit, fd);
 #endif
     }
     REGION_END(direct, RG_GRID_DIRECT);
@@ -893,7 +921,7 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
         if (walking) {
             PATH_STAT(PS_GRID_STEP);
             const uint2 rec = cells[cz * g.nx + cx];
-            if (rec.x != 0xffffffffu) cell_tests<T>(aos, rec.x, rec.y, O, D, a, closest, hit);
+            if (rec.x != 0xffffffffu) cell_tests<T>(aos, rec.x, rec.y, O, D, a, closest, hit, fd);
             // the parameter at which the ray leaves this cell, per axis
             const float bx = (float)(cx + (sx > 0 ? 1 : 0)) * g.cell, bz = (float)(cz + (sz > 0 ? 1 : 0)) * g.cell;
             const float tx = step_x ? (bx - ox) * inv_dx : __builtin_huge_valf();
@@ -1935,10 +1963,21 @@ int primary_rays_in_range(const CAM& c) {
     return std::isfinite(dmax) && dmax + slack < 0x1p30 && dmin - slack > 0x1p-30;
 }
 
+// FastDiv (above ieee_roots): every sphere (centre +- radius) and the lens within 2^18 of the origin.
+template <class CAM>
+int scene_in_range(const rtiow_handle_s* h, const CAM& c) {
+    double reach = 0;
+    for (size_t i = 0; i + 3 < h->host_cr.size(); i += 4)
+        for (int k = 0; k < 3; ++k) reach = std::fmax(reach, std::fabs(h->host_cr[i + k]) + std::fabs(h->host_cr[i + 3]));
+    for (int k = 0; k < 3; ++k)
+        reach = std::fmax(reach, std::fabs((double)c.center[k]) + std::fabs((double)c.defocus_disk_u[k]) + std::fabs((double)c.defocus_disk_v[k]));
+    return !h->host_cr.empty() && std::isfinite(reach) && reach < 0x1p18;
+}
+
 template <class T, class CAM>
 RenderParams<T> make_params(const rtiow_handle_s* h, const CAM& c) {
     RenderParams<T> p;
-    p.primary_len_in_range = primary_rays_in_range(c);
+    p.range_flags = primary_rays_in_range(c) | (scene_in_range(h, c) << 1);
     p.cold.W = c.img_width; p.cold.H = c.img_height; p.cold.S = c.samples_per_pixel; p.B = c.max_depth;
     p.cold.pixel_samples_scale = c.pixel_samples_scale;
     p.center = {c.center[0], c.center[1], c.center[2]};
