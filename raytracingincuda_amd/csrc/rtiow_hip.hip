@@ -38,6 +38,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <mutex>
 #include <vector>
 
@@ -891,51 +892,59 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
         float r0 = __builtin_amdgcn_rcpf(af);
         fd.ra = (T)__builtin_fmaf(__builtin_fmaf(-af, r0, 1.0f), r0, r0);
     }
-    // ---- the direct list: packed trips, every ray
-    {
-        const T* dg = reinterpret_cast<const T*>(smem_raw + g.direct_offset);
-        const int* ids = reinterpret_cast<const int*>(smem_raw + g.direct_ids_offset);
-        const LoopRay<T> r = make_loop_ray(O.x, O.y, O.z, D.x, D.y, D.z, a);
+    // The direct list and the walk, instantiated for both values of fd.on: ONE scalar branch per segment picks the
+    // copy, inside it every quotient's form is fixed at compile time (a branch at each of the eight finishing
+    // sites cost 6 % more scalar instructions).
+    auto direct_list_and_walk = [&](auto fast_tag) __attribute__((always_inline)) {
+        const FastDiv<T> fdc = {fd.ra, decltype(fast_tag)::value};
+        // ---- the direct list: packed trips, every ray
+        {
+            const T* dg = reinterpret_cast<const T*>(smem_raw + g.direct_offset);
+            const int* ids = reinterpret_cast<const int*>(smem_raw + g.direct_ids_offset);
+            const LoopRay<T> r = make_loop_ray(O.x, O.y, O.z, D.x, D.y, D.z, a);
 #ifndef RTIOW_ABLATE_DIRECT
-        for (int s = 0; s < g.n_direct_padded; s += 4) direct_trip<T>(dg, ids, s, r, closest, hit, fd);
+            for (int s = 0; s < g.n_direct_padded; s += 4) direct_trip<T>(dg, ids, s, r, closest, hit, fdc);
 #endif
-    }
-    REGION_END(direct, RG_GRID_DIRECT);
-    // ---- the walk
-    REGION_BEGIN(walk);
-    bool walking = near && crosses;
+        }
+        REGION_END(direct, RG_GRID_DIRECT);
+        // ---- the walk
+        REGION_BEGIN(walk);
+        bool walking = near && crosses;
 #ifdef RTIOW_ABLATE_WALK
-    walking = false;
+        walking = false;
 #endif
-    if (__builtin_amdgcn_ballot_w64(walking) == 0) { REGION_END(walk, RG_GRID_WALK); return; }
-    const T* aos = sizeof(T) == 4 ? reinterpret_cast<const T*>(smem_raw + g.aos_offset) : lds_exact;
-    const uint2* cells = reinterpret_cast<const uint2*>(smem_raw + g.cells_offset);
-    const float px = __builtin_fmaf(t0, dx, ox), pz = __builtin_fmaf(t0, dz, oz);
-    int cx = (int)__builtin_floorf(px * g.inv_cell), cz = (int)__builtin_floorf(pz * g.inv_cell);
-    cx = cx < 0 ? 0 : (cx >= g.nx ? g.nx - 1 : cx);
-    cz = cz < 0 ? 0 : (cz >= g.nz ? g.nz - 1 : cz);
-    const bool step_x = __builtin_fabsf(dx) >= 1e-30f, step_z = __builtin_fabsf(dz) >= 1e-30f;
-    const float inv_dx = step_x ? __builtin_amdgcn_rcpf(dx) : 0.0f, inv_dz = step_z ? __builtin_amdgcn_rcpf(dz) : 0.0f;
-    const int sx = dx > 0.0f ? 1 : -1, sz = dz > 0.0f ? 1 : -1;
-    while (__builtin_amdgcn_ballot_w64(walking) != 0) {
-        if (walking) {
-            PATH_STAT(PS_GRID_STEP);
-            const uint2 rec = cells[cz * g.nx + cx];
-            if (rec.x != 0xffffffffu) cell_tests<T>(aos, rec.x, rec.y, O, D, a, closest, hit, fd);
-            // the parameter at which the ray leaves this cell, per axis
-            const float bx = (float)(cx + (sx > 0 ? 1 : 0)) * g.cell, bz = (float)(cz + (sz > 0 ? 1 : 0)) * g.cell;
-            const float tx = step_x ? (bx - ox) * inv_dx : __builtin_huge_valf();
-            const float tz = step_z ? (bz - oz) * inv_dz : __builtin_huge_valf();
-            const float tnext = __builtin_fminf(tx, tz);
-            const float tend = __builtin_fminf(t1, (float)closest);           // (float) rounds to nearest: covered by eps
-            if (tnext >= tend) walking = false;                               // leaves the slab / the grid, or a nearer hit is known
-            else {
-                if (tx <= tz) cx += sx; else cz += sz;
-                if ((unsigned)cx >= (unsigned)g.nx || (unsigned)cz >= (unsigned)g.nz) walking = false;
+        if (__builtin_amdgcn_ballot_w64(walking) == 0) { REGION_END(walk, RG_GRID_WALK); return; }
+        const T* aos = sizeof(T) == 4 ? reinterpret_cast<const T*>(smem_raw + g.aos_offset) : lds_exact;
+        const uint2* cells = reinterpret_cast<const uint2*>(smem_raw + g.cells_offset);
+        const float px = __builtin_fmaf(t0, dx, ox), pz = __builtin_fmaf(t0, dz, oz);
+        int cx = (int)__builtin_floorf(px * g.inv_cell), cz = (int)__builtin_floorf(pz * g.inv_cell);
+        cx = cx < 0 ? 0 : (cx >= g.nx ? g.nx - 1 : cx);
+        cz = cz < 0 ? 0 : (cz >= g.nz ? g.nz - 1 : cz);
+        const bool step_x = __builtin_fabsf(dx) >= 1e-30f, step_z = __builtin_fabsf(dz) >= 1e-30f;
+        const float inv_dx = step_x ? __builtin_amdgcn_rcpf(dx) : 0.0f, inv_dz = step_z ? __builtin_amdgcn_rcpf(dz) : 0.0f;
+        const int sx = dx > 0.0f ? 1 : -1, sz = dz > 0.0f ? 1 : -1;
+        while (__builtin_amdgcn_ballot_w64(walking) != 0) {
+            if (walking) {
+                PATH_STAT(PS_GRID_STEP);
+                const uint2 rec = cells[cz * g.nx + cx];
+                if (rec.x != 0xffffffffu) cell_tests<T>(aos, rec.x, rec.y, O, D, a, closest, hit, fdc);
+                // the parameter at which the ray leaves this cell, per axis
+                const float bx = (float)(cx + (sx > 0 ? 1 : 0)) * g.cell, bz = (float)(cz + (sz > 0 ? 1 : 0)) * g.cell;
+                const float tx = step_x ? (bx - ox) * inv_dx : __builtin_huge_valf();
+                const float tz = step_z ? (bz - oz) * inv_dz : __builtin_huge_valf();
+                const float tnext = __builtin_fminf(tx, tz);
+                const float tend = __builtin_fminf(t1, (float)closest);           // (float) rounds to nearest: covered by eps
+                if (tnext >= tend) walking = false;                               // leaves the slab / the grid, or a nearer hit is known
+                else {
+                    if (tx <= tz) cx += sx; else cz += sz;
+                    if ((unsigned)cx >= (unsigned)g.nx || (unsigned)cz >= (unsigned)g.nz) walking = false;
+                }
             }
         }
-    }
-    REGION_END(walk, RG_GRID_WALK);
+        REGION_END(walk, RG_GRID_WALK);
+    };
+    if (fd.on) direct_list_and_walk(std::true_type{});
+    else direct_list_and_walk(std::false_type{});
 }
 
 template <class T, int SRC>
