@@ -335,8 +335,15 @@ template <class T> __device__ __forceinline__ V3<T> madd3(T t, V3<T> v, V3<T> w)
     return {RT_FMA(t, v.x, w.x), RT_FMA(t, v.y, w.y), RT_FMA(t, v.z, w.z)};
 }
 template <class T> __device__ __forceinline__ V3<T> scale3(T t, V3<T> v) { return {t * v.x, t * v.y, t * v.z}; }
+__device__ __forceinline__ float inv_sqrt_accepted(float x);
+__device__ __forceinline__ double inv_sqrt_accepted(double x);
 template <class T> __device__ __forceinline__ V3<T> unit3(V3<T> v) {       // vec3.h:105-107, 89-91
-    T inv = (T)1 / Real<T>::sqrt(dot3(v, v));
+    const T dd = dot3(v, v);
+    T inv;
+    // fp32: when every lane here has |v|^2 in [2^-80, 2^80] the wave takes 1/sqrt without the range handling
+    // (inv_sqrt_accepted: 16 instead of 26 instructions, same bits); one lane outside and all take the long form
+    if (sizeof(T) == 4 && __builtin_amdgcn_ballot_w64(!(dd >= (T)0x1p-80 && dd <= (T)0x1p80)) == 0) inv = inv_sqrt_accepted(dd);
+    else inv = (T)1 / Real<T>::sqrt(dd);
     return scale3(inv, v);
 }
 template <class T> __device__ __forceinline__ V3<T> reflect3(V3<T> v, V3<T> n) {   // vec3.h:129-131
@@ -391,15 +398,20 @@ __device__ __forceinline__ void region_add(int region, unsigned long long t0) {
 // The same holds for any operand in [2^-80, 2^80] (square root in [2^-40, 2^40]: v_sqrt_f32 needs no scaling
 // from 2^-96 up, v_div_scale none while the exponents of 1 and the root differ by less than 96): gen_primary
 // uses it for |D|^2 of the primary rays when the host has bounded that for the whole frame.
+// The square-root half on its own: correctly rounded sqrt of a normal x in [2^-90, 2^90] (ieee_roots, behind a wave-wide range test).
+__device__ __forceinline__ float sqrt_in_range(float x) {
+    const float s0 = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s0) - 1u), sp = __uint_as_float(__float_as_uint(s0) + 1u);
+    const float rm = __builtin_fmaf(-sm, s0, x), rp = __builtin_fmaf(-sp, s0, x);
+    const float s = rm <= 0.0f ? sm : s0;
+    return rp > 0.0f ? sp : s;
+}
+__device__ __forceinline__ double sqrt_in_range(double x) { return __builtin_sqrt(x); }   // never selected
 __device__ __forceinline__ float inv_sqrt_accepted(float x) {
 #ifdef RTIOW_GENERIC_RUV_NORMALISATION
     return 1.0f / __builtin_sqrtf(x);
 #else
-    const float s0 = __builtin_amdgcn_sqrtf(x);
-    const float sm = __uint_as_float(__float_as_uint(s0) - 1u), sp = __uint_as_float(__float_as_uint(s0) + 1u);
-    const float rm = __builtin_fmaf(-sm, s0, x), rp = __builtin_fmaf(-sp, s0, x);
-    float s = rm <= 0.0f ? sm : s0;
-    s = rp > 0.0f ? sp : s;
+    const float s = sqrt_in_range(x);
     float r = __builtin_amdgcn_rcpf(s);
     r = __builtin_fmaf(__builtin_fmaf(-s, r, 1.0f), r, r);
     float q = r;                                             // numerator 1: q = 1 * r
@@ -540,7 +552,11 @@ template <class T, bool ANYORDER>
 __device__ __forceinline__ void ieee_roots(int s, T h, T disc, T a, T& closest, int& hit, FastDiv<T> fd) {
     const T tmin = (T)0.001;
     PATH_STAT(PS_IEEE_BLOCK);
-    const T sq = Real<T>::sqrt(disc);                               // :50
+    T sq;                                                           // :50
+    if (fd.on && sizeof(T) == 4 && __builtin_amdgcn_ballot_w64(!(disc >= (T)0x1p-90 && disc <= (T)0x1p90)) == 0)
+        sq = sqrt_in_range(disc);      // every lane here has a normal discriminant well above 2^-96: the IEEE sequence without its range handling
+    else
+        sq = Real<T>::sqrt(disc);
     T root = fd.on ? shared_rcp_quotient(h - sq, a, fd.ra) : (h - sq) / a;   // :53
     auto inside = [&](T r) {
         if (ANYORDER) return (tmin < r) && (r < closest || (r == closest && (unsigned)s < (unsigned)hit));
