@@ -521,7 +521,7 @@ __device__ __forceinline__ bool root_pretest_rejects(T h, T disc, T a, T closest
 // is   d' = div_scale(a), n' = div_scale(n);  r = rcp(d'); r = fma(fma(-d', r, 1), r, r);        <- a only
 //      q = n' r; q = fma(fma(-d', q, n'), r, q); q = div_fmas(fma(-d', q, n'), r, q); div_fixup   <- per quotient
 // and for operands that need no scaling (d' = a, n' = n, flag clear: div_fmas is an fma, div_fixup the identity)
-// its first line depends on the ray alone.  hit_world_grid computes r once per segment (make_fast_div) and every
+// its first line depends on the ray alone.  hit_world_grid computes r once per segment (refined_reciprocal) and every
 // quotient of the segment is the second line's five instructions instead of eleven -- the same instructions on the
 // same values, hence the same bits.  "No scaling" is guaranteed, not tested per quotient: v_div_scale_f32 leaves
 // its operands alone while a is normal, 1/a is normal and -126 < exponent(n) - exponent(a) < 96.  The host vouches
@@ -535,7 +535,24 @@ __device__ __forceinline__ float shared_rcp_quotient(float n, float a, float ra)
     q = __builtin_fmaf(__builtin_fmaf(-a, q, n), ra, q);
     return __builtin_fmaf(__builtin_fmaf(-a, q, n), ra, q);
 }
-__device__ __forceinline__ double shared_rcp_quotient(double n, double a, double) { return n / a; }   // never selected (fp64 keeps n / a)
+// fp64: the compiler's sequence is  d' = div_scale(a), n' = div_scale(n); r = rcp(d'); twice r = fma(r, fma(-d', r, 1), r);
+//                                    q = n' r; div_fixup(div_fmas(fma(-d', q, n'), r, q))
+// -- the same split: six instructions (one of them v_rcp_f64, 16 cycles) per ray, three per quotient.  No scaling
+// while the exponents of n and a differ by less than 768; the bounds above leave 83.
+__device__ __forceinline__ double shared_rcp_quotient(double n, double a, double ra) {
+    const double q = n * ra;
+    return __builtin_fma(__builtin_fma(-a, q, n), ra, q);
+}
+
+__device__ __forceinline__ float refined_reciprocal(float a) {        // the divisor-only half of the fp32 sequence
+    const float r = __builtin_amdgcn_rcpf(a);
+    return __builtin_fmaf(__builtin_fmaf(-a, r, 1.0f), r, r);
+}
+__device__ __forceinline__ double refined_reciprocal(double a) {      // ... and of the fp64 sequence
+    double r = __builtin_amdgcn_rcp(a);
+    r = __builtin_fma(r, __builtin_fma(-a, r, 1.0), r);
+    return __builtin_fma(r, __builtin_fma(-a, r, 1.0), r);
+}
 
 template <class T, bool ANYORDER = false>
 __device__ __forceinline__ void ieee_roots(int s, T h, T disc, T a, T& closest, int& hit, FastDiv<T> fd);
@@ -903,10 +920,9 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
 #endif
     // ---- one reciprocal for every quotient of this segment (FastDiv above ieee_roots)
     FastDiv<T> fd = {(T)0, false};
-    if (sizeof(T) == 4 && (p.range_flags & 2)) {
-        fd.on = __builtin_amdgcn_ballot_w64(!(af >= 0x1p-40f && af <= 0x1p40f)) == 0;
-        float r0 = __builtin_amdgcn_rcpf(af);
-        fd.ra = (T)__builtin_fmaf(__builtin_fmaf(-af, r0, 1.0f), r0, r0);
+    if (p.range_flags & 2) {
+        fd.on = __builtin_amdgcn_ballot_w64(!(a >= (T)0x1p-40 && a <= (T)0x1p40)) == 0;
+        fd.ra = refined_reciprocal(a);
     }
     // The direct list and the walk, instantiated for both values of fd.on: ONE scalar branch per segment picks the
     // copy, inside it every quotient's form is fixed at compile time (a branch at each of the eight finishing
