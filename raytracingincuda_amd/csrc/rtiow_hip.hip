@@ -340,9 +340,9 @@ __device__ __forceinline__ double inv_sqrt_accepted(double x);
 template <class T> __device__ __forceinline__ V3<T> unit3(V3<T> v) {       // vec3.h:105-107, 89-91
     const T dd = dot3(v, v);
     T inv;
-    // fp32: when every lane here has |v|^2 in [2^-80, 2^80] the wave takes 1/sqrt without the range handling
-    // (inv_sqrt_accepted: 16 instead of 26 instructions, same bits); one lane outside and all take the long form
-    if (sizeof(T) == 4 && __builtin_amdgcn_ballot_w64(!(dd >= (T)0x1p-80 && dd <= (T)0x1p80)) == 0) inv = inv_sqrt_accepted(dd);
+    // when every lane here has |v|^2 in [2^-80, 2^80] the wave takes 1/sqrt without the range handling
+    // (inv_sqrt_accepted: fp32 16 instead of 26 instructions, same bits); one lane outside and all take the long form
+    if (__builtin_amdgcn_ballot_w64(!(dd >= (T)0x1p-80 && dd <= (T)0x1p80)) == 0) inv = inv_sqrt_accepted(dd);
     else inv = (T)1 / Real<T>::sqrt(dd);
     return scale3(inv, v);
 }
@@ -394,7 +394,7 @@ __device__ __forceinline__ void region_add(int region, unsigned long long t0) {
 // v_div_fmas is a plain fma) and v_div_fixup (specials only).  What is left is those sequences' own arithmetic,
 // instruction for instruction: raw v_sqrt_f32 (<= 1 ulp) corrected by the two residual tests against its neighbours,
 // then raw v_rcp_f32 with one Newton step and the two quotient refinements.  Same bits as
-// `1.0f / sqrtf(lensq)` (the full-frame goldens compare every pixel); fp64 keeps the generic code.
+// `1.0f / sqrtf(lensq)` (the full-frame goldens compare every pixel); the fp64 twin follows below.
 // The same holds for any operand in [2^-80, 2^80] (square root in [2^-40, 2^40]: v_sqrt_f32 needs no scaling
 // from 2^-96 up, v_div_scale none while the exponents of 1 and the root differ by less than 96): gen_primary
 // uses it for |D|^2 of the primary rays when the host has bounded that for the whole frame.
@@ -406,7 +406,20 @@ __device__ __forceinline__ float sqrt_in_range(float x) {
     const float s = rm <= 0.0f ? sm : s0;
     return rp > 0.0f ? sp : s;
 }
-__device__ __forceinline__ double sqrt_in_range(double x) { return __builtin_sqrt(x); }   // never selected
+// fp64: the compiler's correctly rounded sqrt is v_rsq_f64 and nine multiply-adds (Goldschmidt with two residual
+// corrections) wrapped in a 2^256 pre-scaling of operands below 2^-767 and the zero / infinity pass-through: eight of
+// its eighteen instructions.  The ten in the middle, as emitted:
+__device__ __forceinline__ double sqrt_in_range(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    double d = __builtin_fma(-g, g, x);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
 __device__ __forceinline__ float inv_sqrt_accepted(float x) {
 #ifdef RTIOW_GENERIC_RUV_NORMALISATION
     return 1.0f / __builtin_sqrtf(x);
@@ -419,7 +432,19 @@ __device__ __forceinline__ float inv_sqrt_accepted(float x) {
     return __builtin_fmaf(__builtin_fmaf(-s, q, 1.0f), r, q);
 #endif
 }
-__device__ __forceinline__ double inv_sqrt_accepted(double x) { return 1.0 / __builtin_sqrt(x); }
+// fp64 (accepted lensq in (1e-160, 1], and any operand in [2^-90, 2^90]): the ten instructions above, then 1 / s as
+// the division's own arithmetic with a numerator of 1 (v_rcp_f64, two Newton steps, q = 1 * r, one refinement).
+__device__ __forceinline__ double inv_sqrt_accepted(double x) {
+#ifdef RTIOW_GENERIC_RUV_NORMALISATION
+    return 1.0 / __builtin_sqrt(x);
+#else
+    const double s = sqrt_in_range(x);
+    double r = __builtin_amdgcn_rcp(s);
+    r = __builtin_fma(r, __builtin_fma(-s, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-s, r, 1.0), r);
+    return __builtin_fma(__builtin_fma(-s, r, 1.0), r, r);
+#endif
+}
 
 template <class T> __device__ __forceinline__ V3<T> random_unit_vector(Rng& s) {   // vec3.h:117-127
     // The rejection loop only finds the accepted candidate; its normalisation (an IEEE sqrt and
@@ -476,7 +501,7 @@ __device__ __forceinline__ void gen_primary(const RenderParams<T>& p, int i, int
     D = {ps.x - org.x, ps.y - org.y, ps.z - org.z};
     const T dd = dot3(D, D);
     T inv;
-    if (sizeof(T) == 4 && (p.range_flags & 1)) inv = inv_sqrt_accepted(dd);   // wave-uniform choice, same bits
+    if (p.range_flags & 1) inv = inv_sqrt_accepted(dd);   // wave-uniform choice, same bits
     else inv = (T)1 / Real<T>::sqrt(dd);
     sky_uy = inv * D.y;
 }
@@ -570,7 +595,7 @@ __device__ __forceinline__ void ieee_roots(int s, T h, T disc, T a, T& closest, 
     const T tmin = (T)0.001;
     PATH_STAT(PS_IEEE_BLOCK);
     T sq;                                                           // :50
-    if (fd.on && sizeof(T) == 4 && __builtin_amdgcn_ballot_w64(!(disc >= (T)0x1p-90 && disc <= (T)0x1p90)) == 0)
+    if (fd.on && __builtin_amdgcn_ballot_w64(!(disc >= (T)0x1p-90 && disc <= (T)0x1p90)) == 0)
         sq = sqrt_in_range(disc);      // every lane here has a normal discriminant well above 2^-96: the IEEE sequence without its range handling
     else
         sq = Real<T>::sqrt(disc);
