@@ -932,6 +932,12 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
         REGION_END(fallback, RG_GRID_FALLBACK);
         return;
     }
+    // ---- one reciprocal for every quotient of this segment (FastDiv above ieee_roots)
+    FastDiv<T> fd = {(T)0, false};
+    if (p.range_flags & 2) {
+        fd.on = __builtin_amdgcn_ballot_w64(!(a >= (T)0x1p-40 && a <= (T)0x1p40)) == 0;
+        fd.ra = refined_reciprocal(a);
+    }
     REGION_BEGIN(direct);
 #ifdef RTIOW_PROBE_DIRECT
     {
@@ -939,16 +945,10 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
         const T* dg = reinterpret_cast<const T*>(smem_raw + g.direct_offset);
         const int* ids = reinterpret_cast<const int*>(smem_raw + g.direct_ids_offset);
         const LoopRay<T> r = make_loop_ray(o2.x, o2.y, o2.z, d2.x, d2.y, d2.z, a);
-        for (int s = 0; s < g.n_direct_padded; s += 4) direct_trip<T>(dg, ids, s, r, c2, h2, FastDiv<T>{(T)0, false});
+        for (int s = 0; s < g.n_direct_padded; s += 4) direct_trip<T>(dg, ids, s, r, c2, h2, fd);
         RT_KEEP1(c2); RT_KEEP1(h2);
     }
 #endif
-    // ---- one reciprocal for every quotient of this segment (FastDiv above ieee_roots)
-    FastDiv<T> fd = {(T)0, false};
-    if (p.range_flags & 2) {
-        fd.on = __builtin_amdgcn_ballot_w64(!(a >= (T)0x1p-40 && a <= (T)0x1p40)) == 0;
-        fd.ra = refined_reciprocal(a);
-    }
     // The direct list and the walk, instantiated for both values of fd.on: ONE scalar branch per segment picks the
     // copy, inside it every quotient's form is fixed at compile time (a branch at each of the eight finishing
     // sites cost 6 % more scalar instructions).
