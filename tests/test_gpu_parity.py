@@ -540,6 +540,27 @@ def test_primary_ray_normalisation_paths_match_the_oracle(rt, oracle):
         assert _same_bits(a, want), log2_len
 
 
+@pytest.mark.parametrize("prec", [32, 64])
+def test_short_ieee_forms_on_a_far_translated_scene(rt, oracle, prec):
+    """The root quotients use one reciprocal per segment only while the host can vouch for the operand ranges
+    (every coordinate of spheres and lens below 2^18).  Scene 3 and its camera moved by
+    1e5 (inside that bound: short forms, on coordinates where fp32 has lost five digits) and by 3e5 (outside:
+    the compiler's sequences) must both give the oracle's bits."""
+    W, H, S, B = 64, 40, 3, 10
+    for shift in (1.0e5, 3.0e5):
+        sc = rt.build_scene(3, prec)
+        off = np.array([shift, 0.0, -shift])
+        sc["center_radius"][:, 0] += np.asarray(off[0], sc["center_radius"].dtype)
+        sc["center_radius"][:, 2] += np.asarray(off[2], sc["center_radius"].dtype)
+        cam = rt.camera(prec, W, H, S, B)
+        for k in range(3):
+            cam.center[k] += off[k]; cam.pixel00_loc[k] += off[k]
+        a, _ = _render_cam(rt, prec, sc, cam, rt.SCENE_GRID)
+        want, _ = oracle.render(prec, compact(sc), cam, 1227)
+        assert _same_bits(a, want), (prec, shift)
+        assert float(np.asarray(a, np.float64).std()) > 0.01           # a picture, not a constant
+
+
 def _adversarial_rays(rng, cr, plan, n_each):
     """Ray families a render rarely or never produces, around the grid of `plan` (tests/test_grid_plan._plan)."""
     x0, z0, cell, nx, nz = plan["x0"], plan["z0"], plan["cell"], plan["nx"], plan["nz"]
