@@ -446,6 +446,13 @@ __device__ __forceinline__ double inv_sqrt_accepted(double x) {
 #endif
 }
 
+// sqrt(x) for every live lane of the wave: the short form when all their operands are normal and mid-range (one
+// ballot), else the compiler's sequence for everyone -- the same bits either way.
+template <class T> __device__ __forceinline__ T sqrt_wave_checked(T x) {
+    if (__builtin_amdgcn_ballot_w64(!(x >= (T)0x1p-90 && x <= (T)0x1p90)) == 0) return sqrt_in_range(x);
+    return Real<T>::sqrt(x);
+}
+
 template <class T> __device__ __forceinline__ V3<T> random_unit_vector(Rng& s) {   // vec3.h:117-127
     // The rejection loop only finds the accepted candidate; its normalisation (an IEEE sqrt and
     // divide, ~30 instructions) runs once after the loop instead of in every round the wave
@@ -881,15 +888,17 @@ __device__ __forceinline__ void cell_tests(const T* aos, unsigned rec_lo, unsign
 }
 
 // Clip of o + t d against [lo, hi] on one axis, folded into [t0, t1].  Raw reciprocal: see eps above.
-__device__ __forceinline__ void clip_axis(float o, float d, float lo, float hi, float& t0, float& t1) {
+// Returns the raw reciprocal of d it used (0 for a parallel ray): the walk steps with the same values.
+__device__ __forceinline__ float clip_axis(float o, float d, float lo, float hi, float& t0, float& t1) {
     if (__builtin_fabsf(d) < 1e-30f) {
         if (!(o >= lo && o <= hi)) t1 = -__builtin_huge_valf();
-    } else {
-        const float inv = __builtin_amdgcn_rcpf(d);
-        const float ta = (lo - o) * inv, tb = (hi - o) * inv;
-        t0 = __builtin_fmaxf(t0, __builtin_fminf(ta, tb));
-        t1 = __builtin_fminf(t1, __builtin_fmaxf(ta, tb));
+        return 0.0f;
     }
+    const float inv = __builtin_amdgcn_rcpf(d);
+    const float ta = (lo - o) * inv, tb = (hi - o) * inv;
+    t0 = __builtin_fmaxf(t0, __builtin_fminf(ta, tb));
+    t1 = __builtin_fminf(t1, __builtin_fmaxf(ta, tb));
+    return inv;
 }
 
 template <class T>
@@ -922,8 +931,8 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
         }
     }
     clip_axis(oy, dy, ylo, yhi, t0, t1);
-    clip_axis(ox, dx, xlo, xhi, t0, t1);
-    clip_axis(oz, dz, zlo, zhi, t0, t1);
+    const float inv_dx = clip_axis(ox, dx, xlo, xhi, t0, t1);
+    const float inv_dz = clip_axis(oz, dz, zlo, zhi, t0, t1);
     const bool crosses = !sane || t0 <= t1;
     REGION_END(setup, RG_GRID_SETUP);
     if (__builtin_amdgcn_ballot_w64(!near && crosses) != 0) {
@@ -978,7 +987,6 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
         cx = cx < 0 ? 0 : (cx >= g.nx ? g.nx - 1 : cx);
         cz = cz < 0 ? 0 : (cz >= g.nz ? g.nz - 1 : cz);
         const bool step_x = __builtin_fabsf(dx) >= 1e-30f, step_z = __builtin_fabsf(dz) >= 1e-30f;
-        const float inv_dx = step_x ? __builtin_amdgcn_rcpf(dx) : 0.0f, inv_dz = step_z ? __builtin_amdgcn_rcpf(dz) : 0.0f;
         const int sx = dx > 0.0f ? 1 : -1, sz = dz > 0.0f ? 1 : -1;
         while (__builtin_amdgcn_ballot_w64(walking) != 0) {
             if (walking) {
@@ -1085,11 +1093,10 @@ __device__ __forceinline__ bool shade_step(const RenderParams<T>& p, const T* ld
         const T ri = front ? rec[9] : rec[8];
         const V3<T> ud = unit3(D);
         const T cos_theta = Real<T>::fmin(-dot3(ud, nrm), (T)1);
-        const T sin_theta = Real<T>::sqrt(RT_FMA(-cos_theta, cos_theta, (T)1));
+        const T sin_theta = sqrt_wave_checked(RT_FMA(-cos_theta, cos_theta, (T)1));
         bool reflect_it = ri * sin_theta > (T)1;
         if (!reflect_it) {
-            T r0 = ((T)1 - ri) / ((T)1 + ri);                           // material.h:62-66
-            r0 = r0 * r0;
+            const T r0 = front ? rec[4] : rec[5];                       // material.h:62-66: ((1 - ri) / (1 + ri))^2, computed by upload_scene in T
             const float x = (float)((T)1 - cos_theta);
             const float x2 = x * x;
             const float p5 = (x2 * x2) * x;                              // powf(x,5), see DESIGN.md
@@ -1101,7 +1108,7 @@ __device__ __forceinline__ bool shade_step(const RenderParams<T>& p, const T* ld
             nd = reflect3(ud, nrm);
         } else {                                                         // vec3.h:133-138
             const V3<T> perp = scale3(ri, madd3(cos_theta, nrm, ud));
-            const T k = -Real<T>::sqrt(Real<T>::fabs((T)1 - dot3(perp, perp)));
+            const T k = -sqrt_wave_checked(Real<T>::fabs((T)1 - dot3(perp, perp)));
             nd = madd3(k, nrm, perp);
         }
     } else {
@@ -2069,8 +2076,13 @@ int upload_scene(rtiow_handle_s* h, int n, const T* cr, const T* af, const T* ri
         const T cx = cr[4 * i], cy = cr[4 * i + 1], cz = cr[4 * i + 2], r = cr[4 * i + 3];
         if (type[i] < 0 || type[i] > 2) return fail_arg(h, RTIOW_E_BADARG, "material type out of range");
         ga.insert(ga.end(), {cx, cy, cz, (T)(r * r)});          // hittable.h:45 radius*radius
+        // words 4..7: albedo and fuzz; a dielectric uses neither (material.h:70), its record carries Schlick's
+        // r0^2 = ((1 - ri) / (1 + ri))^2 for ri = 1/eta (front face) and ri = eta (back face) instead, computed here
+        // with the operations of material.h:62-66 in T (no contraction on the host either)
+        auto r0sq = [](T ri_) { T r0 = ((T)1 - ri_) / ((T)1 + ri_); return (T)(r0 * r0); };
+        const bool glass = type[i] == RTIOW_DIELECTRIC;
         st.insert(st.end(), {cx, cy, cz, (T)((T)1 / r),         // vec3.h:89-91 (1/t)*v
-                             af[4 * i], af[4 * i + 1], af[4 * i + 2], af[4 * i + 3],
+                             glass ? r0sq((T)((T)1 / ri[i])) : af[4 * i], glass ? r0sq(ri[i]) : af[4 * i + 1], af[4 * i + 2], af[4 * i + 3],
                              ri[i], (T)((T)1 / ri[i]),          // material.h:73 1.0f/refraction_index
                              (T)type[i], (T)0});
         ++m;
