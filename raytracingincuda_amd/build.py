@@ -43,6 +43,15 @@ def _newer(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+def hip_includes():
+    """The device / library headers rtiow_hip.hip is made of (csrc/device, csrc/library)."""
+    out = []
+    for sub in ("device", "library"):
+        d = os.path.join(CSRC, sub)
+        out += [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith((".h", ".inc"))]
+    return out
+
+
 def _run(cmd, verbose):
     if verbose:
         print("+", " ".join(cmd), flush=True)
@@ -66,7 +75,7 @@ def build(force=False, verbose=True):
 
     hip_srcs = [os.path.join(CSRC, "rtiow_hip.hip"), os.path.join(CSRC, "rtiow_group.hip")]
     hip_so = os.path.join(LIB, "librtiow_hip.so")
-    if force or _newer(hip_so, hip_srcs + [me, os.path.join(CSRC, "xorwow_jump67.inc")] + headers):
+    if force or _newer(hip_so, hip_srcs + hip_includes() + [me] + headers):
         # librccl is NOT linked: rtiow_group.hip dlopens it on first use (-ldl for old glibc)
         _run([_hipcc()] + HIP_FLAGS + ["-o", hip_so] + hip_srcs + ["-ldl"], verbose)
 

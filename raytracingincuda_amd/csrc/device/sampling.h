@@ -1,0 +1,62 @@
+// sampling.h -- random_unit_vector, primary ray generation (vec3.h:109-127, camera.h:73-76, :145-155)
+// Part of the single gfx950 translation unit rtiow_hip.hip (included there, in this order; internal linkage).
+#pragma once
+#include "vecmath.h"
+
+namespace {
+
+template <class T> __device__ __forceinline__ V3<T> random_unit_vector(Rng& s) {   // vec3.h:117-127
+    // The rejection loop only finds the accepted candidate; its normalisation (an IEEE sqrt and
+    // divide, ~30 instructions) runs once after the loop instead of in every round the wave
+    // executes for its slowest lane.  Same draws, same arithmetic on the accepted candidate.
+    T x, y, z, lensq;
+    PATH_STAT(PS_RUV_CALL);
+    REGION_BEGIN(ruv);
+    for (;;) {
+        PATH_STAT(PS_RUV_ROUND);
+        T u0, u1, u2;
+        Real<T>::uniform3(s, u0, u1, u2);
+        x = RT_FMA(u0, (T)2, (T)-1);
+        y = RT_FMA(u1, (T)2, (T)-1);
+        z = RT_FMA(u2, (T)2, (T)-1);
+        lensq = RT_FMA(z, z, RT_FMA(y, y, x * x));
+        if (Real<T>::ruv_eps < lensq && lensq <= (T)1) break;
+    }
+    REGION_END(ruv, RG_RUV_ROUNDS);
+    const T inv = inv_sqrt_accepted(lensq);
+    return {inv * x, inv * y, inv * z};
+}
+
+// One primary ray: camera.h:145-155 (+ :73-76, vec3.h:109-115).  Also returns the y
+// component of the PRIMARY ray's unit direction, all the sky term needs (camera.h:121).
+template <class T>
+__device__ __forceinline__ void gen_primary(const RenderParams<T>& p, int i, int j, Rng& s,
+                                            V3<T>& O, V3<T>& D, T& sky_uy) {
+    PATH_STAT(PS_GEN_PRIMARY);
+    T ox = Real<T>::uniform(s) - (T)0.5;
+    T oy = Real<T>::uniform(s) - (T)0.5;
+    T fi = (T)i + ox, fj = (T)j + oy;
+    V3<T> ps = madd3(fj, p.dv, madd3(fi, p.du, p.pixel00));
+    V3<T> org = p.center;
+    if (!(p.defocus_angle <= (T)0)) {
+        T px, py;
+        for (;;) {
+            PATH_STAT(PS_DISK_ROUND);
+            T u0, u1;
+            Real<T>::uniform2(s, u0, u1);
+            px = RT_FMA((T)2, u0, (T)-1);
+            py = RT_FMA((T)2, u1, (T)-1);
+            if (RT_FMA(py, py, px * px) < (T)1) break;
+        }
+        org = madd3(py, p.ddv, madd3(px, p.ddu, p.center));
+    }
+    O = org;
+    D = {ps.x - org.x, ps.y - org.y, ps.z - org.z};
+    const T dd = dot3(D, D);
+    T inv;
+    if (p.range_flags & 1) inv = inv_sqrt_accepted(dd);   // wave-uniform choice, same bits
+    else inv = (T)1 / Real<T>::sqrt(dd);
+    sky_uy = inv * D.y;
+}
+
+}  // namespace

@@ -44,2608 +44,23 @@
 
 #include "rtiow.h"
 
-namespace {
-
-// =====================================================================================
-// XORWOW: state in registers; skip-ahead matrices built on the host.
-// =====================================================================================
-struct Rng { uint32_t v0, v1, v2, v3, v4, d; };
-
-__device__ __forceinline__ uint32_t rng_next(Rng& s) {
-    uint32_t t = s.v0 ^ (s.v0 >> 2);
-    s.v0 = s.v1; s.v1 = s.v2; s.v2 = s.v3; s.v3 = s.v4;
-    // gfx950's three-input bit operation (truth table 0x96 = a^b^c) takes one of the four xors: 6 instead
-    // of 7 vector instructions per draw (profiles/r02_ab_xorwow_bitop3.jsonl: -2.4 % SQ_INSTS_VALU, -1.2 % time)
-    // t << 1 as t + t: on gfx950 v_lshlrev_b32 issues at 5.3 cycles per wave-instruction, v_add_u32 at 3.7
-    // (bin/valu_cost); the compiler turns a source-level t + t back into the shift, hence the one-line asm.
-    uint32_t t2;
-    asm("v_add_u32 %0, %1, %1" : "=v"(t2) : "v"(t));
-    s.v4 = __builtin_amdgcn_bitop3_b32(s.v4, s.v4 << 4, t, 0x96) ^ t2;
-    s.d += 362437u;
-    return s.v4 + s.d;
-}
-
-// Two / three draws at once with the state rotated IN PLACE (fp32 rejection loops).  A loop whose round
-// draws k numbers rotates the five state words by k places per trip; the compiler materialises that as five
-// register copies at the back edge.  Tied operands leave nothing to copy at the back edge, and inside the block
-// a rotation by three takes two moves and one by two takes three: 20 instead of 23 vector instructions for
-// three draws, 15 instead of 17 for two.  Draw i of the block is then (new word) + d + i * 362437.
-// (t << 1 is written t + t: v_add_u32 issues faster than v_lshlrev_b32, see rng_next.)
-__device__ __forceinline__ void rng_step3(Rng& s) {      // afterwards the draws are v2 + d1, v3 + d2, v4 + d3
-    uint32_t t1, t2, t3, c;
-    asm("v_lshrrev_b32 %5, 2, %0\n\t"
-        "v_lshrrev_b32 %6, 2, %1\n\t"
-        "v_lshrrev_b32 %7, 2, %2\n\t"
-        "v_xor_b32 %5, %5, %0\n\t"
-        "v_xor_b32 %6, %6, %1\n\t"
-        "v_xor_b32 %7, %7, %2\n\t"
-        "v_mov_b32 %0, %3\n\t"
-        "v_mov_b32 %1, %4\n\t"
-        "v_lshlrev_b32 %8, 4, %4\n\t"
-        "v_bitop3_b32 %2, %4, %8, %5 bitop3:0x96\n\t"
-        "v_add_u32 %5, %5, %5\n\t"
-        "v_xor_b32 %2, %2, %5\n\t"
-        "v_lshlrev_b32 %8, 4, %2\n\t"
-        "v_bitop3_b32 %3, %2, %8, %6 bitop3:0x96\n\t"
-        "v_add_u32 %6, %6, %6\n\t"
-        "v_xor_b32 %3, %3, %6\n\t"
-        "v_lshlrev_b32 %8, 4, %3\n\t"
-        "v_bitop3_b32 %4, %3, %8, %7 bitop3:0x96\n\t"
-        "v_add_u32 %7, %7, %7\n\t"
-        "v_xor_b32 %4, %4, %7"
-        : "+v"(s.v0), "+v"(s.v1), "+v"(s.v2), "+v"(s.v3), "+v"(s.v4), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(c));
-}
-__device__ __forceinline__ void rng_step2(Rng& s) {      // afterwards the draws are v3 + d1, v4 + d2
-    uint32_t t1, t2, c;
-    asm("v_lshrrev_b32 %5, 2, %0\n\t"
-        "v_lshrrev_b32 %6, 2, %1\n\t"
-        "v_xor_b32 %5, %5, %0\n\t"
-        "v_xor_b32 %6, %6, %1\n\t"
-        "v_mov_b32 %0, %2\n\t"
-        "v_mov_b32 %1, %3\n\t"
-        "v_lshlrev_b32 %7, 4, %4\n\t"
-        "v_bitop3_b32 %3, %4, %7, %5 bitop3:0x96\n\t"
-        "v_add_u32 %5, %5, %5\n\t"
-        "v_mov_b32 %2, %4\n\t"
-        "v_xor_b32 %3, %3, %5\n\t"
-        "v_lshlrev_b32 %7, 4, %3\n\t"
-        "v_bitop3_b32 %4, %3, %7, %6 bitop3:0x96\n\t"
-        "v_add_u32 %6, %6, %6\n\t"
-        "v_xor_b32 %4, %4, %6"
-        : "+v"(s.v0), "+v"(s.v1), "+v"(s.v2), "+v"(s.v3), "+v"(s.v4), "=&v"(t1), "=&v"(t2), "=&v"(c));
-}
-
-template <class T> struct Real;
-template <> struct Real<float> {
-    // curand_uniform: (0,1]
-    static __device__ __forceinline__ float uniform(Rng& s) {
-        uint32_t x = rng_next(s);
-        return __builtin_fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
-    }
-    static __device__ __forceinline__ float from_u32(uint32_t x) {
-        return __builtin_fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
-    }
-    static __device__ __forceinline__ void uniform2(Rng& s, float& a, float& b) {
-#ifdef RTIOW_NO_INPLACE_RNG
-        a = uniform(s); b = uniform(s);
-#else
-        rng_step2(s);
-        a = from_u32(s.v3 + (s.d + 362437u)); s.d += 2u * 362437u; b = from_u32(s.v4 + s.d);
-#endif
-    }
-    static __device__ __forceinline__ void uniform3(Rng& s, float& a, float& b, float& c) {
-#ifdef RTIOW_NO_INPLACE_RNG
-        a = uniform(s); b = uniform(s); c = uniform(s);
-#else
-        rng_step3(s);
-        a = from_u32(s.v2 + (s.d + 362437u)); b = from_u32(s.v3 + (s.d + 2u * 362437u)); s.d += 3u * 362437u; c = from_u32(s.v4 + s.d);
-#endif
-    }
-    static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-    static __device__ __forceinline__ float sqrt(float a) { return __builtin_sqrtf(a); }
-    static __device__ __forceinline__ float fmin(float a, float b) { return __builtin_fminf(a, b); }
-    static __device__ __forceinline__ float fmax(float a, float b) { return __builtin_fmaxf(a, b); }
-    static __device__ __forceinline__ float fabs(float a) { return __builtin_fabsf(a); }
-    static constexpr float near_zero = 1e-6f;   // vec3.h:50
-    static constexpr float ruv_eps = 1e-8f;     // vec3.h:124
-};
-template <> struct Real<double> {
-    // curand_uniform_double (XORWOW): 53 bits from two draws
-    static __device__ __forceinline__ double uniform(Rng& s) {
-        uint32_t x = rng_next(s);
-        uint32_t y = rng_next(s);
-        uint64_t z = (uint64_t)x ^ ((uint64_t)y << 21);
-        return __builtin_fma((double)z, 1.1102230246251565e-16, 5.5511151231257827e-17);
-    }
-    static __device__ __forceinline__ double from_u32(uint32_t x) {
-        return __builtin_fma((double)x, 1.1102230246251565e-16, 5.5511151231257827e-17);
-    }
-    static __device__ __forceinline__ void uniform2(Rng& s, double& a, double& b) { a = uniform(s); b = uniform(s); }
-    static __device__ __forceinline__ void uniform3(Rng& s, double& a, double& b, double& c) { a = uniform(s); b = uniform(s); c = uniform(s); }
-    static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-    static __device__ __forceinline__ double sqrt(double a) { return __builtin_sqrt(a); }
-    static __device__ __forceinline__ double fmin(double a, double b) { return __builtin_fmin(a, b); }
-    static __device__ __forceinline__ double fmax(double a, double b) { return __builtin_fmax(a, b); }
-    static __device__ __forceinline__ double fabs(double a) { return __builtin_fabs(a); }
-    static constexpr double near_zero = 1e-8;   // GlobalDouble vec3.h:50
-    static constexpr double ruv_eps = 1e-160;   // GlobalDouble vec3.h:125
-};
-
-constexpr int XW_BITS = 160;
-constexpr int XW_WORDS = 5;
-constexpr int XW_JUMPS = 32;                         // subsequence index bits supported
-constexpr size_t XW_MAT_WORDS = (size_t)XW_BITS * XW_WORDS;
-
-// jump: [XW_JUMPS][160][5]; column `bit` of matrix b is the state reached from basis bit.
-// All lanes walk the same (b, bit) order, so the column reads are wave-uniform scalar loads.
-__global__ void __launch_bounds__(256)
-rng_init_kernel(uint32_t* __restrict__ states, const uint32_t* __restrict__ jump, uint32_t d0,
-                uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t s4,
-                int W, int H, int local_rows, int rank, int nranks, int strip_rows) {
-    const int npix = W * local_rows;
-    const int lp = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lp >= npix) return;
-    const int jl = lp / W, i = lp - jl * W;
-    const int j = ((jl / strip_rows) * nranks + rank) * strip_rows + (jl % strip_rows);
-    const uint32_t seq = (uint32_t)(j * W + i);       // camera.h:134 pixel_index, rtweekend.h:49
-    uint32_t v[XW_WORDS] = {s0, s1, s2, s3, s4};
-    for (int b = 0; b < XW_JUMPS; ++b) {
-        if (!((seq >> b) & 1u)) continue;
-        const uint32_t* m = jump + (size_t)b * XW_MAT_WORDS;
-        uint32_t o[XW_WORDS] = {0, 0, 0, 0, 0};
-        for (int w = 0; w < XW_WORDS; ++w) {
-            const uint32_t word = v[w];
-            for (int bit = 0; bit < 32; ++bit) {
-                const uint32_t mask = 0u - ((word >> bit) & 1u);
-                const uint32_t* c = m + (size_t)(w * 32 + bit) * XW_WORDS;
-#pragma unroll
-                for (int k = 0; k < XW_WORDS; ++k) o[k] ^= c[k] & mask;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < XW_WORDS; ++k) v[k] = o[k];
-    }
-    // SoA so that the render kernel's 6 loads per lane are coalesced.
-    states[0 * (size_t)npix + lp] = v[0];
-    states[1 * (size_t)npix + lp] = v[1];
-    states[2 * (size_t)npix + lp] = v[2];
-    states[3 * (size_t)npix + lp] = v[3];
-    states[4 * (size_t)npix + lp] = v[4];
-    states[5 * (size_t)npix + lp] = d0;               // 2^67*k draws leave the Weyl counter unchanged
-    (void)H;
-}
-
-// =====================================================================================
-// render
-// =====================================================================================
-template <class T> struct V3 { T x, y, z; };
-
-// Uniform grid over the small spheres of the scene (hit_world_grid).  x/z run over the cells, the
-// y extent of the gridded spheres is one slab.  All coordinates are fp32 and relative to nothing:
-// x0/z0 are subtracted by the kernel.  Offsets are bytes from the start of dynamic LDS.
-struct GridParams {
-    int use_grid;
-    int nx, nz;
-    float x0, z0, cell, inv_cell;     // cell (ix, iz) covers [x0 + ix*cell, x0 + (ix+1)*cell) x [z0 + iz*cell, ...)
-    float ylo, yhi;                   // slab of the registered (inflated) spheres
-    float far2;                       // |O - ctr|^2 above this: the per-sphere registration margin no longer covers the reference's rounding noise
-    float core_lo[3], core_hi[3];     // box of the gridded spheres' CENTRES (far rays are clipped against it, inflated per ray)
-    float rmax2, cmax;                // largest gridded radius squared; largest |C - ctr| over the gridded spheres
-    int n_direct_padded;              // spheres every ray tests exactly (too big for a cell, or the overflow of a full cell), padded to x4
-    int cells_offset, aos_offset, direct_offset, direct_ids_offset;
-    const unsigned char* __restrict__ blob;   // cells | aos | direct table | direct ids, as laid out in LDS from cells_offset on
-    int blob_bytes;
-};
-
-// Launch parameters, split by how often the kernel needs them.  The HOT part (camera, table
-// offsets, loop bounds) stays in SGPRs for the whole kernel.  The COLD part (buffer pointers, image
-// and shard geometry, sort hand-over) is needed only when a lane takes a new pixel or finishes one:
-// it is read with scalar loads from the kernarg segment at those sites (cold_of), so it does not
-// occupy ~35 SGPRs during the path loop (the all-by-value form spilled 45 SGPRs to VGPR lanes, with
-// 75 v_readlane/v_writelane moves inside the loop).
-template <class T> struct ColdParams {
-    int W, H, S;
-    T pixel_samples_scale;
-    const uint32_t* __restrict__ rng; // [6][npix_local] SoA
-    T* __restrict__ fb;               // [local_rows][W][3]
-    int local_rows, rank, nranks, strip_rows;
-    int bx, by;                       // tile (block) shape in pixels (static schedule)
-    int wave_tiles;                   // 1: lanes of a wave form 8x8 tiles inside the block
-    unsigned long long* seg_counter;  // COUNT variant only: [0] total hit_world calls (path segments) of this launch, [2] the longest per-pixel chain
-    unsigned int* work_counter;       // SCHED_PERSISTENT: next unassigned pixel slot (zeroed per launch)
-    // SCHED_SORTED (two phases of the persistent kernel): first sample of this launch, the
-    // per-pixel state carried between the phases, and the cost-sorted hand-out order.
-    int s_begin;                      // samples [s_begin, s_end) of every pixel
-    const uint32_t* __restrict__ rng_in;   // [6][npix] SoA state at sample s_begin
-    // SCHED_SORTED hand-over between the prepass and the main launch: ONE record per pixel
-    // (MidState<T>: RNG state after sample s_end-1 + colour sum), so that the main launch, which
-    // visits the pixels in cost order, fetches one or two cache lines per pixel instead of nine
-    // (SoA cost 630 MB of fetches per frame for 83 MB of state).
-    const unsigned char* __restrict__ mid_in;   // main launch: state at sample s_begin (nullptr: rng_in, zero sum)
-    unsigned char* __restrict__ mid_out;        // prepass: park the state (nullptr: final launch, the pixel is stored)
-    uint32_t* __restrict__ cost_out;  // prepass only: segments the pixel ran in this launch
-    const int* __restrict__ order;    // slot -> local pixel (or -1), nullptr: 8x8 tiles bottom-up
-    int total_slots;
-    int first_pools;                  // 1: wave w starts with pool w (the work counter then starts at the wave count)
-    // Solo waves: the first solo_waves*solo_lanes slots of the order (the heaviest pixels) go solo_lanes each to
-    // wave 0 of the first solo_waves workgroups, which take nothing else until those pixels are done.
-    int solo_waves, solo_lanes;
-    unsigned long long* timeline;     // COUNT variant, optional: per wave {t_start, t_exhausted, t_end, iters_normal, iters_coop, pixels, 0, 0}
-};
-
-template <class T> struct RenderParams {
-    int B, s_end;                     // bounce limit; this launch renders samples [cold.s_begin, s_end)
-    int lane_cap;                     // lanes of a wave that take pixels (64; fewer when the launch is underfilled, see launch_render)
-    int range_flags;                  // host-checked operand ranges.  bit 0 (primary_rays_in_range): |D|^2 of every primary ray lies well
-                                      // inside [2^-80, 2^80]; bit 1 (scene_in_range): every coordinate of spheres and lens is below 2^18
-    V3<T> center, pixel00, du, dv;
-    T defocus_angle;
-    V3<T> ddu, ddv;
-    int n, n_padded;                  // spheres, and the table length padded to a multiple of 4
-    const T* __restrict__ geom_a;     // [n_padded][4] cx,cy,cz,r*r (sphere loop; padding never hits)
-    // fp32 screening table (hit_world_screened): recentred centres and q' = |C'|^2 - r^2 - margin,
-    // pair-interleaved like geom_a; staged in LDS behind geom_a (screen_offset bytes)
-    const float* __restrict__ geom_s;
-    int use_screen, screen_offset;
-    T ctr_x, ctr_y, ctr_z, omax2;     // recentring point; omax2 = 2 Cmax of the per-ray margin term
-    // everything the shade step needs about the sphere that was hit, 12 T per sphere:
-    // {cx,cy,cz,1/r | albedo r,g,b,fuzz | eta, 1/eta, material type, 0}
-    const T* __restrict__ shade_tbl;
-    int shade_in_lds;                 // 1: the table is staged behind the loop table in LDS (shade_offset bytes)
-    int shade_offset;
-    int coop_offset;                  // SCHED_PERSISTENT: byte offset of the per-wave coop scratch in LDS
-    int use_grid;                     // RTIOW_SCENE_GRID: hit_world_grid (its description below is read through grid_of)
-    GridParams grid;
-    ColdParams<T> cold;
-};
-
-// The cold half of the kernel's own argument, re-read from the kernarg segment.  The empty asm
-// makes the base pointer opaque at every call site, so the scalar loads stay inside the (rare)
-// block that needs them instead of being hoisted to the kernel entry and kept live.
-template <class T>
-__device__ __forceinline__ const __attribute__((address_space(4))) ColdParams<T>& cold_of(const RenderParams<T>&) {
-    typedef const __attribute__((address_space(4))) char* kptr;
-    kptr k = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(k));
-    return *(const __attribute__((address_space(4))) ColdParams<T>*)(k + offsetof(RenderParams<T>, cold));
-}
-// Same for the grid description: ~25 scalars that only hit_world_grid needs, loaded at its entry.
-template <class T>
-__device__ __forceinline__ const __attribute__((address_space(4))) GridParams& grid_of(const RenderParams<T>&) {
-    typedef const __attribute__((address_space(4))) char* kptr;
-    kptr k = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(k));
-    return *(const __attribute__((address_space(4))) GridParams*)(k + offsetof(RenderParams<T>, grid));
-}
-
-#define RT_FMA(a, b, c) Real<T>::fma((a), (b), (c))
-
-// ---- double-execution probes (scripts/cost_probe.sh; compiled out by default).  With -DRTIOW_PROBE_<X> the
-// component X runs a SECOND time on copies of its inputs and the results are thrown away behind an opaque
-// asm, so the image is unchanged and the growth of SQ_INSTS_VALU is exactly what X costs.
-#define RT_KEEP1(v) asm volatile("" :: "v"(v))
-template <class T> __device__ __forceinline__ void rt_opaque(V3<T>& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z)); }
-__device__ __forceinline__ void rt_opaque(Rng& r) { asm volatile("" : "+v"(r.v0), "+v"(r.v1), "+v"(r.v2), "+v"(r.v3), "+v"(r.v4), "+v"(r.d)); }
-
-
-template <class T> __device__ __forceinline__ T dot3(V3<T> u, V3<T> v) {   // vec3.h:93-97
-    return RT_FMA(u.z, v.z, RT_FMA(u.y, v.y, u.x * v.x));
-}
-template <class T> __device__ __forceinline__ V3<T> madd3(T t, V3<T> v, V3<T> w) {   // w + t*v
-    return {RT_FMA(t, v.x, w.x), RT_FMA(t, v.y, w.y), RT_FMA(t, v.z, w.z)};
-}
-template <class T> __device__ __forceinline__ V3<T> scale3(T t, V3<T> v) { return {t * v.x, t * v.y, t * v.z}; }
-__device__ __forceinline__ float inv_sqrt_accepted(float x);
-__device__ __forceinline__ double inv_sqrt_accepted(double x);
-template <class T> __device__ __forceinline__ V3<T> unit3(V3<T> v) {       // vec3.h:105-107, 89-91
-    const T dd = dot3(v, v);
-    T inv;
-    // when every lane here has |v|^2 in [2^-80, 2^80] the wave takes 1/sqrt without the range handling
-    // (inv_sqrt_accepted: fp32 16 instead of 26 instructions, same bits); one lane outside and all take the long form
-    if (__builtin_amdgcn_ballot_w64(!(dd >= (T)0x1p-80 && dd <= (T)0x1p80)) == 0) inv = inv_sqrt_accepted(dd);
-    else inv = (T)1 / Real<T>::sqrt(dd);
-    return scale3(inv, v);
-}
-template <class T> __device__ __forceinline__ V3<T> reflect3(V3<T> v, V3<T> n) {   // vec3.h:129-131
-    T k = (T)2 * dot3(v, n);
-    return madd3(-k, n, v);
-}
-// ---- optional execution profile (build with -DRTIOW_PATH_STATS, `python -m raytracingincuda_amd.build
-// --stats`): per region, how many times a WAVE executed it and with how many active lanes.  The
-// kernel is bound by the vector instructions it issues, and a divergent region costs its full
-// instruction count whenever one lane needs it, so (wave executions x static instruction count)
-// is the time budget (scripts/path_stats_probe.py).  Compiled out by default.
-#ifdef RTIOW_PATH_STATS
-enum { PS_ITERATION = 0, PS_RUV_CALL, PS_RUV_ROUND, PS_DISK_ROUND, PS_GEN_PRIMARY, PS_SHADE_HIT, PS_SKY, PS_DIELECTRIC, PS_METAL,
-       PS_EXACT_BLOCK, PS_FINISH_CALL, PS_IEEE_BLOCK, PS_SECOND_DIV, PS_SCHLICK_DRAW, PS_REFILL, PS_FINISH_PIXEL, PS_GRID_STEP, PS_COUNT };
-__device__ unsigned long long g_path_stats[2 * PS_COUNT];
-__device__ __forceinline__ void path_stat(int region) {
-    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    if (lane == __builtin_ctzll(act)) {
-        atomicAdd(&g_path_stats[2 * region], 1ull);
-        atomicAdd(&g_path_stats[2 * region + 1], (unsigned long long)__builtin_popcountll(act));
-    }
-}
-#define PATH_STAT(r) path_stat(r)
-// Region clocks of the same build: shader cycles a WAVE spends between two points, summed over all
-// waves (s_memtime; the reads themselves cost ~10 % and other waves' issue slots are included, so
-// only the proportions mean something).  scripts/path_stats_probe.py prints them.
-enum { RG_REFILL = 0, RG_GEN_PRIMARY, RG_HIT_WORLD, RG_HIT_COOP, RG_SHADE, RG_ACCUMULATE, RG_GRID_SETUP, RG_GRID_DIRECT, RG_GRID_WALK, RG_GRID_FALLBACK,
-       RG_RUV_ROUNDS, RG_LOOP_TOTAL, RG_COUNT };
-__device__ unsigned long long g_region_cycles[RG_COUNT];
-__device__ __forceinline__ void region_add(int region, unsigned long long t0) {
-    const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
-    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd(&g_region_cycles[region], dt);
-}
-#define REGION_BEGIN(name) const unsigned long long rg_##name = __builtin_amdgcn_s_memtime()
-#define REGION_END(name, region) region_add(region, rg_##name)
-#else
-#define PATH_STAT(r) ((void)0)
-#define REGION_BEGIN(name) ((void)0)
-#define REGION_END(name, region) ((void)0)
-#endif
-
-// 1 / sqrt(lensq) of an ACCEPTED candidate (vec3.h:126: p / sqrt(lensq)), i.e. the IEEE square root followed by the
-// IEEE reciprocal, for an operand known to lie in (1e-8, 1].  The compiler's correctly rounded sequences (15 + 11
-// instructions) spend 10 of them on what such an operand never needs: the 2^32 pre-scaling of a square root below
-// 2^-96 with its un-scaling, the zero / infinity pass-through, v_div_scale on both operands (no scaling for a
-// numerator 1 and a denominator in [1e-4, 1]: the scaled values ARE the operands and the flag is clear, so
-// v_div_fmas is a plain fma) and v_div_fixup (specials only).  What is left is those sequences' own arithmetic,
-// instruction for instruction: raw v_sqrt_f32 (<= 1 ulp) corrected by the two residual tests against its neighbours,
-// then raw v_rcp_f32 with one Newton step and the two quotient refinements.  Same bits as
-// `1.0f / sqrtf(lensq)` (the full-frame goldens compare every pixel); the fp64 twin follows below.
-// The same holds for any operand in [2^-80, 2^80] (square root in [2^-40, 2^40]: v_sqrt_f32 needs no scaling
-// from 2^-96 up, v_div_scale none while the exponents of 1 and the root differ by less than 96): gen_primary
-// uses it for |D|^2 of the primary rays when the host has bounded that for the whole frame.
-// The square-root half on its own: correctly rounded sqrt of a normal x in [2^-90, 2^90] (ieee_roots, behind a wave-wide range test).
-__device__ __forceinline__ float sqrt_in_range(float x) {
-    const float s0 = __builtin_amdgcn_sqrtf(x);
-    const float sm = __uint_as_float(__float_as_uint(s0) - 1u), sp = __uint_as_float(__float_as_uint(s0) + 1u);
-    const float rm = __builtin_fmaf(-sm, s0, x), rp = __builtin_fmaf(-sp, s0, x);
-    const float s = rm <= 0.0f ? sm : s0;
-    return rp > 0.0f ? sp : s;
-}
-// fp64: the compiler's correctly rounded sqrt is v_rsq_f64 and nine multiply-adds (Goldschmidt with two residual
-// corrections) wrapped in a 2^256 pre-scaling of operands below 2^-767 and the zero / infinity pass-through: eight of
-// its eighteen instructions.  The ten in the middle, as emitted:
-__device__ __forceinline__ double sqrt_in_range(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = y * 0.5;
-    const double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    double d = __builtin_fma(-g, g, x);
-    h = __builtin_fma(h, r, h);
-    g = __builtin_fma(d, h, g);
-    d = __builtin_fma(-g, g, x);
-    return __builtin_fma(d, h, g);
-}
-__device__ __forceinline__ float inv_sqrt_accepted(float x) {
-#ifdef RTIOW_GENERIC_RUV_NORMALISATION
-    return 1.0f / __builtin_sqrtf(x);
-#else
-    const float s = sqrt_in_range(x);
-    float r = __builtin_amdgcn_rcpf(s);
-    r = __builtin_fmaf(__builtin_fmaf(-s, r, 1.0f), r, r);
-    float q = r;                                             // numerator 1: q = 1 * r
-    q = __builtin_fmaf(__builtin_fmaf(-s, q, 1.0f), r, q);
-    return __builtin_fmaf(__builtin_fmaf(-s, q, 1.0f), r, q);
-#endif
-}
-// fp64 (accepted lensq in (1e-160, 1], and any operand in [2^-90, 2^90]): the ten instructions above, then 1 / s as
-// the division's own arithmetic with a numerator of 1 (v_rcp_f64, two Newton steps, q = 1 * r, one refinement).
-__device__ __forceinline__ double inv_sqrt_accepted(double x) {
-#ifdef RTIOW_GENERIC_RUV_NORMALISATION
-    return 1.0 / __builtin_sqrt(x);
-#else
-    const double s = sqrt_in_range(x);
-    double r = __builtin_amdgcn_rcp(s);
-    r = __builtin_fma(r, __builtin_fma(-s, r, 1.0), r);
-    r = __builtin_fma(r, __builtin_fma(-s, r, 1.0), r);
-    return __builtin_fma(__builtin_fma(-s, r, 1.0), r, r);
-#endif
-}
-
-// sqrt(x) for every live lane of the wave: the short form when all their operands are normal and mid-range (one
-// ballot), else the compiler's sequence for everyone -- the same bits either way.
-template <class T> __device__ __forceinline__ T sqrt_wave_checked(T x) {
-    if (__builtin_amdgcn_ballot_w64(!(x >= (T)0x1p-90 && x <= (T)0x1p90)) == 0) return sqrt_in_range(x);
-    return Real<T>::sqrt(x);
-}
-
-template <class T> __device__ __forceinline__ V3<T> random_unit_vector(Rng& s) {   // vec3.h:117-127
-    // The rejection loop only finds the accepted candidate; its normalisation (an IEEE sqrt and
-    // divide, ~30 instructions) runs once after the loop instead of in every round the wave
-    // executes for its slowest lane.  Same draws, same arithmetic on the accepted candidate.
-    T x, y, z, lensq;
-    PATH_STAT(PS_RUV_CALL);
-    REGION_BEGIN(ruv);
-    for (;;) {
-        PATH_STAT(PS_RUV_ROUND);
-        T u0, u1, u2;
-        Real<T>::uniform3(s, u0, u1, u2);
-        x = RT_FMA(u0, (T)2, (T)-1);
-        y = RT_FMA(u1, (T)2, (T)-1);
-        z = RT_FMA(u2, (T)2, (T)-1);
-        lensq = RT_FMA(z, z, RT_FMA(y, y, x * x));
-        if (Real<T>::ruv_eps < lensq && lensq <= (T)1) break;
-#ifdef RTIOW_ABLATE_RUV_ROUNDS
-        lensq = (T)0.5; break;
-#endif
-    }
-    REGION_END(ruv, RG_RUV_ROUNDS);
-    const T inv = inv_sqrt_accepted(lensq);
-    return {inv * x, inv * y, inv * z};
-}
-
-// One primary ray: camera.h:145-155 (+ :73-76, vec3.h:109-115).  Also returns the y
-// component of the PRIMARY ray's unit direction, all the sky term needs (camera.h:121).
-template <class T>
-__device__ __forceinline__ void gen_primary(const RenderParams<T>& p, int i, int j, Rng& s,
-                                            V3<T>& O, V3<T>& D, T& sky_uy) {
-    PATH_STAT(PS_GEN_PRIMARY);
-    T ox = Real<T>::uniform(s) - (T)0.5;
-    T oy = Real<T>::uniform(s) - (T)0.5;
-    T fi = (T)i + ox, fj = (T)j + oy;
-    V3<T> ps = madd3(fj, p.dv, madd3(fi, p.du, p.pixel00));
-    V3<T> org = p.center;
-    if (!(p.defocus_angle <= (T)0)) {
-        T px, py;
-        for (;;) {
-            PATH_STAT(PS_DISK_ROUND);
-            T u0, u1;
-            Real<T>::uniform2(s, u0, u1);
-            px = RT_FMA((T)2, u0, (T)-1);
-            py = RT_FMA((T)2, u1, (T)-1);
-            if (RT_FMA(py, py, px * px) < (T)1) break;
-#ifdef RTIOW_ABLATE_DISK_ROUNDS
-            break;
-#endif
-        }
-        org = madd3(py, p.ddv, madd3(px, p.ddu, p.center));
-    }
-    O = org;
-    D = {ps.x - org.x, ps.y - org.y, ps.z - org.z};
-    const T dd = dot3(D, D);
-    T inv;
-    if (p.range_flags & 1) inv = inv_sqrt_accepted(dd);   // wave-uniform choice, same bits
-    else inv = (T)1 / Real<T>::sqrt(dd);
-    sky_uy = inv * D.y;
-}
-
-// raw hardware square root (v_sqrt_f32 / v_sqrt_f64, error <= 2^-22 relative): used ONLY inside the
-// conservative pre-test below, never for a value that reaches the image.
-__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ double fast_sqrt(double x) { return __builtin_amdgcn_sqrt(x); }
-
-// Second half of hit_sphere (hittable.h:50-57) once the discriminant is known to be >= 0.
-//
-// Most spheres that get here are then rejected (behind the origin, or farther than the hit
-// already found), after an IEEE sqrt and up to two IEEE divisions (~56 instructions).  A cheap
-// pre-test drops a sphere ONLY when the exact code below provably would: all roots of one ray
-// share the divisor a > 0, so they order like their numerators n = h -+ sqrt(disc);
-//   (behind) n2 + e <  tmin*a*(1-2^-20)  =>  both exact roots <= tmin;
-//   (far)    n1 - e >  closest*a*(1+2^-20) =>  exact near root >= closest, hence the far one too.
-// e bounds |n_fast - n_ref|: the raw sqrt is within 1 ulp (2^-23 relative) and the reference's
-// IEEE sqrt within half an ulp, so the two square roots differ by at most 0.75 * 2^-22 * sqrt;
-// the additions h -+ sqrt round once on each side (2^-24 |n| each, |n| <= |h| + sqrt).  Hence
-// e = 2^-22 (|h| + sqrt) + 2^-60 (the constant covers a raw sqrt that flushes a denormal
-// discriminant to zero).  Rays leaving the ground sphere (|h|, sqrt ~ 1000, far root = rounding
-// noise ~1e-4) are what the tight bound is for: with 2^-20 every one of them fell through to
-// the IEEE code.  In doubt the exact code runs, so the result is unchanged.
-//
-// ANYORDER: the caller does not visit the spheres in index order (hit_world_grid).  The reference's
-// loop keeps the FIRST sphere among equal roots (`root < closest_so_far` is strict, hittable.h:54-56),
-// i.e. its result is the lexicographic minimum of (t, index); out of order that is `root < closest,
-// or root == closest and a lower index`.  Testing a sphere twice changes nothing.
-template <class T>
-__device__ __forceinline__ bool root_pretest_rejects(T h, T disc, T a, T closest) {
-    const T tmin = (T)0.001;
-    const T kappa = (T)2.384185791015625e-07;                      // 2^-22
-    const T sq_approx = fast_sqrt(disc);
-    const T e = RT_FMA(kappa, Real<T>::fabs(h) + sq_approx, (T)8.673617379884035e-19);   // + 2^-60
-    const T behind_bound = (tmin * a) * (T)0.99999904632568359375;  // tmin*a*(1-2^-20)
-    const T far_bound = (closest * a) * (T)1.00000095367431640625; // closest*a*(1+2^-20); inf while nothing is hit
-    return (int)((h + sq_approx) + e < behind_bound) | (int)((h - sq_approx) - e > far_bound);   // one branch, not two
-}
-
-// All roots of one ray are divided by the same a = d.d.  The correctly rounded fp32 division the compiler emits
-// is   d' = div_scale(a), n' = div_scale(n);  r = rcp(d'); r = fma(fma(-d', r, 1), r, r);        <- a only
-//      q = n' r; q = fma(fma(-d', q, n'), r, q); q = div_fmas(fma(-d', q, n'), r, q); div_fixup   <- per quotient
-// and for operands that need no scaling (d' = a, n' = n, flag clear: div_fmas is an fma, div_fixup the identity)
-// its first line depends on the ray alone.  hit_world_grid computes r once per segment (refined_reciprocal) and every
-// quotient of the segment is the second line's five instructions instead of eleven -- the same instructions on the
-// same values, hence the same bits.  "No scaling" is guaranteed, not tested per quotient: v_div_scale_f32 leaves
-// its operands alone while a is normal, 1/a is normal and -126 < exponent(n) - exponent(a) < 96.  The host vouches
-// for the scene (range_flags bit 1: every coordinate of spheres and lens below 2^18, so |oc| < 2^21), the wave
-// checks a in [2^-40, 2^40] for all its lanes (else the whole wave divides the long way for that segment), which
-// bounds |n| = |h -+ sqrt(disc)| by 2^43 and the exponent difference by 83.  A quotient so small that the IEEE
-// sequence would scale it is < 2^-80 on both paths and fails `tmin < root` either way; only accepted roots are stored.
-template <class T> struct FastDiv { T ra; bool on; };          // on is wave-uniform
-__device__ __forceinline__ float shared_rcp_quotient(float n, float a, float ra) {
-    float q = n * ra;
-    q = __builtin_fmaf(__builtin_fmaf(-a, q, n), ra, q);
-    return __builtin_fmaf(__builtin_fmaf(-a, q, n), ra, q);
-}
-// fp64: the compiler's sequence is  d' = div_scale(a), n' = div_scale(n); r = rcp(d'); twice r = fma(r, fma(-d', r, 1), r);
-//                                    q = n' r; div_fixup(div_fmas(fma(-d', q, n'), r, q))
-// -- the same split: six instructions (one of them v_rcp_f64, 16 cycles) per ray, three per quotient.  No scaling
-// while the exponents of n and a differ by less than 768; the bounds above leave 83.
-__device__ __forceinline__ double shared_rcp_quotient(double n, double a, double ra) {
-    const double q = n * ra;
-    return __builtin_fma(__builtin_fma(-a, q, n), ra, q);
-}
-
-__device__ __forceinline__ float refined_reciprocal(float a) {        // the divisor-only half of the fp32 sequence
-    const float r = __builtin_amdgcn_rcpf(a);
-    return __builtin_fmaf(__builtin_fmaf(-a, r, 1.0f), r, r);
-}
-__device__ __forceinline__ double refined_reciprocal(double a) {      // ... and of the fp64 sequence
-    double r = __builtin_amdgcn_rcp(a);
-    r = __builtin_fma(r, __builtin_fma(-a, r, 1.0), r);
-    return __builtin_fma(r, __builtin_fma(-a, r, 1.0), r);
-}
-
-template <class T, bool ANYORDER = false>
-__device__ __forceinline__ void ieee_roots(int s, T h, T disc, T a, T& closest, int& hit, FastDiv<T> fd);
-
-template <class T, bool ANYORDER = false>
-__device__ __forceinline__ void finish_sphere_test(int s, T h, T disc, T a, T& closest, int& hit, FastDiv<T> fd = FastDiv<T>{(T)0, false}) {
-    PATH_STAT(PS_FINISH_CALL);
-    if (root_pretest_rejects<T>(h, disc, a, closest)) return;
-    ieee_roots<T, ANYORDER>(s, h, disc, a, closest, hit, fd);
-}
-
-// hittable.h:50-57 proper.
-template <class T, bool ANYORDER>
-__device__ __forceinline__ void ieee_roots(int s, T h, T disc, T a, T& closest, int& hit, FastDiv<T> fd) {
-    const T tmin = (T)0.001;
-    PATH_STAT(PS_IEEE_BLOCK);
-    T sq;                                                           // :50
-    if (fd.on && __builtin_amdgcn_ballot_w64(!(disc >= (T)0x1p-90 && disc <= (T)0x1p90)) == 0)
-        sq = sqrt_in_range(disc);      // every lane here has a normal discriminant well above 2^-96: the IEEE sequence without its range handling
-    else
-        sq = Real<T>::sqrt(disc);
-    T root = fd.on ? shared_rcp_quotient(h - sq, a, fd.ra) : (h - sq) / a;   // :53
-    auto inside = [&](T r) {
-        if (ANYORDER) return (tmin < r) && (r < closest || (r == closest && (unsigned)s < (unsigned)hit));
-        return (tmin < r) && (r < closest);
-    };
-    bool ok = inside(root);                                         // :54
-    if (!ok) {
-        PATH_STAT(PS_SECOND_DIV);
-        root = fd.on ? shared_rcp_quotient(h + sq, a, fd.ra) : (h + sq) / a;   // :55
-        ok = inside(root);                                          // :56
-    }
-    if (ok) { closest = root; hit = s; }                            // hittable.h:88-92
-}
-
-// First half of hit_sphere (hittable.h:42-47) for the four spheres s..s+3 of one trip:
-// h = d.oc and disc = h*h - a*c, each element with exactly the reference's operation sequence.
-//
-// fp32: the table is PAIR-INTERLEAVED -- {cxA,cxB, cyA,cyB, czA,czB, r2A,r2B} per pair of
-// spheres -- so the twelve operations run as v_pk_add/mul/fma_f32 on two spheres at once:
-// 24 packed VALU per trip instead of 48 (per-element IEEE results are unchanged).
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-template <class T> struct Trip { T h0, h1, h2, h3, d0, d1, d2, d3; };
-
-// The ray as the sphere loop wants it: fp32 keeps every component splatted over a register
-// pair (the second operand of the packed instructions), fp64 keeps plain scalars.
-template <class T> struct LoopRay;
-template <> struct LoopRay<float> { v2f ox, oy, oz, dx, dy, dz, aa; float a; };
-template <> struct LoopRay<double> { double ox, oy, oz, dx, dy, dz, a; };
-
-__device__ __forceinline__ LoopRay<float> make_loop_ray(float ox, float oy, float oz, float dx, float dy, float dz, float a) {
-    // The empty asm makes each component an opaque VGPR value, so the splats are built with
-    // register moves (hipcc otherwise round-trips the ray through scratch to form the pairs).
-    asm volatile("" : "+v"(ox), "+v"(oy), "+v"(oz), "+v"(dx), "+v"(dy), "+v"(dz), "+v"(a));
-    LoopRay<float> r;
-    r.ox.x = ox; r.ox.y = ox; r.oy.x = oy; r.oy.y = oy; r.oz.x = oz; r.oz.y = oz;
-    r.dx.x = dx; r.dx.y = dx; r.dy.x = dy; r.dy.y = dy; r.dz.x = dz; r.dz.y = dz;
-    r.aa.x = a; r.aa.y = a; r.a = a;
-    return r;
-}
-__device__ __forceinline__ LoopRay<double> make_loop_ray(double ox, double oy, double oz, double dx, double dy, double dz, double a) {
-    return {ox, oy, oz, dx, dy, dz, a};
-}
-
-__device__ __forceinline__ void pair_discriminants(v4f lo, v4f hi, const LoopRay<float>& r, v2f& hh, v2f& dd) {
-    const v2f cx = {lo.x, lo.y}, cy = {lo.z, lo.w}, cz = {hi.x, hi.y}, r2 = {hi.z, hi.w};
-    const v2f ocx = cx - r.ox, ocy = cy - r.oy, ocz = cz - r.oz;                                    // :42
-    hh = __builtin_elementwise_fma(r.dz, ocz, __builtin_elementwise_fma(r.dy, ocy, r.dx * ocx));    // :44
-    const v2f c = __builtin_elementwise_fma(ocz, ocz, __builtin_elementwise_fma(ocy, ocy, ocx * ocx)) - r2;   // :45
-    dd = __builtin_elementwise_fma(hh, hh, -(r.aa * c));                                            // :47
-}
-
-__device__ __forceinline__ Trip<float> trip_discriminants(const float* g, int s, const LoopRay<float>& r) {
-    const v4f* g4 = reinterpret_cast<const v4f*>(g + 4 * s);
-    const v4f p0 = g4[0], p1 = g4[1], p2 = g4[2], p3 = g4[3];
-    v2f ha, da, hb, db;
-    pair_discriminants(p0, p1, r, ha, da);
-    pair_discriminants(p2, p3, r, hb, db);
-    return {ha.x, ha.y, hb.x, hb.y, da.x, da.y, db.x, db.y};
-}
-
-// fp64: plain {cx,cy,cz,r2} per sphere (no packed f64 on gfx950).
-__device__ __forceinline__ void sphere_discriminant(const double* g, int s, const LoopRay<double>& r, double& h, double& disc) {
-    const double cx = g[4 * s + 0], cy = g[4 * s + 1], cz = g[4 * s + 2], r2 = g[4 * s + 3];
-    const double ocx = cx - r.ox, ocy = cy - r.oy, ocz = cz - r.oz;                    // :42
-    h = __builtin_fma(r.dz, ocz, __builtin_fma(r.dy, ocy, r.dx * ocx));                // :44
-    const double c = __builtin_fma(ocz, ocz, __builtin_fma(ocy, ocy, ocx * ocx)) - r2; // :45
-    disc = __builtin_fma(h, h, -(r.a * c));                                            // :47
-}
-__device__ __forceinline__ Trip<double> trip_discriminants(const double* g, int s, const LoopRay<double>& r) {
-    Trip<double> t;
-    sphere_discriminant(g, s + 0, r, t.h0, t.d0);
-    sphere_discriminant(g, s + 1, r, t.h1, t.d1);
-    sphere_discriminant(g, s + 2, r, t.h2, t.d2);
-    sphere_discriminant(g, s + 3, r, t.h3, t.d3);
-    return t;
-}
-
-// One trip = four spheres: discriminants, ONE wave-level branch on max(disc0..3) >= 0 (a lane
-// reaches a sphere's line in only ~4 % of the trips for the reference scenes), and the IEEE
-// sqrt/divide tail only inside it, in index order.
-template <class T>
-__device__ __forceinline__ void sphere_trip(const T* g, int s, const LoopRay<T>& r, T& closest, int& hit) {
-    const Trip<T> t = trip_discriminants(g, s, r);
-    const T m = Real<T>::fmax(Real<T>::fmax(t.d0, t.d1), Real<T>::fmax(t.d2, t.d3));
-    if (m >= (T)0) {                                                          // :48 for any of the four
-        if (t.d0 >= (T)0) finish_sphere_test<T>(s + 0, t.h0, t.d0, r.a, closest, hit);
-        if (t.d1 >= (T)0) finish_sphere_test<T>(s + 1, t.h1, t.d1, r.a, closest, hit);
-        if (t.d2 >= (T)0) finish_sphere_test<T>(s + 2, t.h2, t.d2, r.a, closest, hit);
-        if (t.d3 >= (T)0) finish_sphere_test<T>(s + 3, t.h3, t.d3, r.a, closest, hit);
-    }
-}
-
-// hit_world (hittable.h:80-98): every sphere tested exactly, in index order.  The table is
-// padded to a multiple of 4 with never-hit entries (r^2 = -1e12 => disc < 0).
-template <class T, int SRC>
-__device__ __forceinline__ void hit_world_direct(const RenderParams<T>& p, const T* lds_geom, V3<T> O, V3<T> D, T a,
-                                                 T& closest, int& hit) {
-    const T* g = (SRC == RTIOW_SCENE_LDS) ? lds_geom : p.geom_a;
-    const LoopRay<T> r = make_loop_ray(O.x, O.y, O.z, D.x, D.y, D.z, a);
-    for (int s = 0; s < p.n_padded; s += 4) sphere_trip<T>(g, s, r, closest, hit);
-}
-
-// hit_sphere for ONE sphere, scalar, exactly the reference's arithmetic (used by the screened
-// loop for its rare candidates; the table is the pair-interleaved fp32 one).
-__device__ __forceinline__ void exact_sphere_test_f32(const float* g, int s, V3<float> O, V3<float> D, float a, float& closest, int& hit) {
-    PATH_STAT(PS_EXACT_BLOCK);
-    const int base = (s >> 1) * 8 + (s & 1);
-    const float cx = g[base], cy = g[base + 2], cz = g[base + 4], r2 = g[base + 6];
-    const float ocx = cx - O.x, ocy = cy - O.y, ocz = cz - O.z;                                   // :42
-    const float h = __builtin_fmaf(D.z, ocz, __builtin_fmaf(D.y, ocy, D.x * ocx));                 // :44
-    const float c = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx)) - r2;            // :45
-    const float disc = __builtin_fmaf(h, h, -(a * c));                                            // :47
-    if (disc >= 0.0f) finish_sphere_test<float>(s, h, disc, a, closest, hit);                      // :48-57
-}
-
-// hit_world with an 8-operation SCREEN (packed fp32) in front of the reference's 12-operation test.
-//
-// In exact arithmetic h = d.(C-O) = d.C - d.O and c = |C-O|^2 - r^2 = (|C|^2 - r^2) + |O|^2 - 2 O.C,
-// so with the per-ray constants k1 = d.O', k2 = |O'|^2, m = -2 O' (O' = O - centre) and the
-// per-sphere constant q = |C'|^2 - r^2 (C' = C - centre, precomputed) a sphere costs
-//     h~ = fma(dz,Cz', fma(dy,Cy', fma(dx,Cx', -k1)))      3
-//     c~ = fma(mz,Cz', fma(my,Cy', fma(mx,Cx', q + k2)))   4
-//     disc~ = fma(h~,h~, -c~)        (d pre-scaled to unit length, so a = 1)   1      = 8 instead of 12
-// (8 v_pk per PAIR of spheres).  The unit direction uses the raw v_rsq (2^-22): only the sign of
-// disc~ matters and disc/a has the same sign as disc, the rsq error is covered by the margin.
-// disc~ is NOT the reference's discriminant (different roundings, cancellation), so it only
-// SCREENS: with E = 2^-18 a ((|C'|+|O'|)^2 + r^2) bounding |disc~ - Disc| + |disc_ref - Disc|
-// (derivation in DESIGN.md, constant 45u of slack-free bound vs 64u used), twice that margin is
-// subtracted from c~: the sphere's share 2^-17(|C'|^2 + r^2) is baked into q' by the host, the
-// ray's share 2^-17(2 Cmax |O'| + |O'|^2) (Cmax = max |C'| over the screened spheres) is folded
-// into k2, so that        disc_ref >= 0   =>   disc~' >= 0        for every ray and sphere.
-// A sphere with disc~' < 0 therefore fails the reference's `discriminant < 0` test (hittable.h:48)
-// and is skipped like there; every other sphere is re-tested with the reference's exact
-// arithmetic (exact_sphere_test_f32), in index order.  Spheres the bound would make useless
-// (|C'| > 64: the ground) get q' = -1e30 and are always re-tested.  Result: bit-identical.
-__device__ __forceinline__ void exact_sphere_test_f64(const double* g, int s, V3<double> O, V3<double> D, double a, double& closest, int& hit) {
-    const double cx = g[4 * s], cy = g[4 * s + 1], cz = g[4 * s + 2], r2 = g[4 * s + 3];
-    const double ocx = cx - O.x, ocy = cy - O.y, ocz = cz - O.z;                                   // :42
-    const double h = __builtin_fma(D.z, ocz, __builtin_fma(D.y, ocy, D.x * ocx));                  // :44
-    const double c = __builtin_fma(ocz, ocz, __builtin_fma(ocy, ocy, ocx * ocx)) - r2;             // :45
-    const double disc = __builtin_fma(h, h, -(a * c));                                             // :47
-    if (disc >= 0.0) finish_sphere_test<double>(s, h, disc, a, closest, hit);                      // :48-57
-}
-
-__device__ __forceinline__ void exact_sphere_test(const float* g, int s, V3<float> O, V3<float> D, float a, float& closest, int& hit) {
-    exact_sphere_test_f32(g, s, O, D, a, closest, hit);
-}
-__device__ __forceinline__ void exact_sphere_test(const double* g, int s, V3<double> O, V3<double> D, double a, double& closest, int& hit) {
-    exact_sphere_test_f64(g, s, O, D, a, closest, hit);
-}
-
-// The screen itself always runs in packed fp32, for both precisions: it only has to be
-// conservative.  fp64 rays are rounded to fp32 first (one more 2^-24 relative perturbation of O'
-// and d, of the kind the margin already covers for the recentring), and the fp64 reference
-// discriminant carries ~2^-53 instead of 18 * 2^-24 of rounding, so the fp32 margins hold a
-// fortiori; candidates are re-tested with the exact fp64 arithmetic.  21 instead of 36 issue
-// cycles per sphere (v_pk_fma_f32 vs v_fma_f64, bin/valu_cost).
-template <class T>
-__device__ __forceinline__ void hit_world_screened(const RenderParams<T>& p, const T* lds_exact, const float* lds_screen,
-                                                   V3<T> O, V3<T> D, T a, T& closest, int& hit) {
-    float ox = (float)(O.x - p.ctr_x), oy = (float)(O.y - p.ctr_y), oz = (float)(O.z - p.ctr_z);
-    float dx = (float)D.x, dy = (float)D.y, dz = (float)D.z;
-    const float af = sizeof(T) == 4 ? (float)a : __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-    const float rs = __builtin_amdgcn_rsqf(af);   // screen only: |d^| = 1 +- 2^-22
-    dx *= rs; dy *= rs; dz *= rs;
-    float nk1 = -__builtin_fmaf(dz, oz, __builtin_fmaf(dy, oy, dx * ox));
-    float k2 = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
-    k2 = k2 - 7.62939453125e-06f * __builtin_fmaf((float)p.omax2, fast_sqrt(k2), k2);   // - 2^-17 (2 Cmax |O'| + |O'|^2); p.omax2 holds 2 Cmax (1 + 2^-20): raw sqrt
-    float mx = -2.0f * ox, my = -2.0f * oy, mz = -2.0f * oz;
-    asm volatile("" : "+v"(nk1), "+v"(k2), "+v"(mx), "+v"(my), "+v"(mz), "+v"(dx), "+v"(dy), "+v"(dz));
-    const v2f vnk1 = {nk1, nk1}, vk2 = {k2, k2}, vmx = {mx, mx}, vmy = {my, my}, vmz = {mz, mz};
-    const v2f vdx = {dx, dx}, vdy = {dy, dy}, vdz = {dz, dz};
-    for (int s = 0; s < p.n_padded; s += 4) {
-        const v4f* g4 = reinterpret_cast<const v4f*>(lds_screen + 4 * s);
-        const v4f p0 = g4[0], p1 = g4[1], p2 = g4[2], p3 = g4[3];
-        v2f dsc[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const v4f lo = q ? p2 : p0, hi = q ? p3 : p1;
-            const v2f cx = {lo.x, lo.y}, cy = {lo.z, lo.w}, cz = {hi.x, hi.y}, qq = {hi.z, hi.w};
-            const v2f hh = __builtin_elementwise_fma(vdz, cz, __builtin_elementwise_fma(vdy, cy, __builtin_elementwise_fma(vdx, cx, vnk1)));
-            const v2f cc = __builtin_elementwise_fma(vmz, cz, __builtin_elementwise_fma(vmy, cy, __builtin_elementwise_fma(vmx, cx, qq + vk2)));
-            dsc[q] = __builtin_elementwise_fma(hh, hh, -cc);
-        }
-        const float m = __builtin_fmaxf(__builtin_fmaxf(dsc[0].x, dsc[0].y), __builtin_fmaxf(dsc[1].x, dsc[1].y));
-        if (!(m < 0.0f)) {                        // some sphere of the trip may pass hittable.h:48 (NaNs are kept)
-            if (!(dsc[0].x < 0.0f)) exact_sphere_test(lds_exact, s + 0, O, D, a, closest, hit);
-            if (!(dsc[0].y < 0.0f)) exact_sphere_test(lds_exact, s + 1, O, D, a, closest, hit);
-            if (!(dsc[1].x < 0.0f)) exact_sphere_test(lds_exact, s + 2, O, D, a, closest, hit);
-            if (!(dsc[1].y < 0.0f)) exact_sphere_test(lds_exact, s + 3, O, D, a, closest, hit);
-        }
-    }
-}
-
-// =====================================================================================
-// hit_world over a uniform grid (RTIOW_SCENE_GRID, the default).
-//
-// The screen above still costs every ray 8 operations per sphere.  The host therefore also bins
-// the SMALL spheres of the scene into a 2-D grid of cells over x/z (one slab in y), at most four
-// per cell (build_grid_tables); a lane walks only the cells its own ray crosses while it is inside
-// the slab and tests their spheres with the reference's exact arithmetic.  Spheres that do not fit
-// a cell (the ground, the three unit spheres) or overflow a full one form the DIRECT list, which
-// every ray tests exactly in packed trips first.  Measured on the headline scene a wave walks 1.7
-// cells per iteration (its longest lane) instead of screening 125 spheres.
-//
-// Why the result is unchanged.  The reference's nearest hit is the lexicographic minimum of
-// (t, index) over the spheres whose hit_sphere succeeds; a sphere's own candidate root does not
-// depend on the others (finish_sphere_test).  It therefore suffices that every sphere the
-// reference COULD accept is tested, with the reference's arithmetic and the ANYORDER tie rule:
-//  * hit_sphere can only succeed if its computed discriminant is >= 0, and that discriminant
-//    differs from the real-number one by at most E = 18u(|oc|^2 + r^2) (u = 2^-24),
-//    so the ray's LINE passes within sqrt(r^2 + E) of the centre, and the point at the accepted
-//    root lies inside that inflated ball (its squared distance from the centre is r^2 + (computed
-//    - real discriminant));
-//  * for origins within sqrt(far2) of the scene centre the host bounds E once and registers
-//    sphere i in every cell that its bounding square inflated to sqrt(r_i^2 + E) + eps touches;
-//    eps (2^-16 of the largest coordinate in play, >= 25x the rounding of the walk below) lets the
-//    walk be computed in plain fp32 with raw reciprocals: the cells it visits stay within eps of
-//    the true ray, and every point of the true ray inside an inflated ball has that sphere
-//    registered in every cell within eps of it;
-//  * the walk is clipped to the box of the registered (inflated) spheres and to t >= 0 (a sphere
-//    behind the origin has both roots < tmin unless the origin is inside it, and then it is
-//    registered in the origin's cell);
-//  * the walk stops once the next cell boundary lies beyond the nearest accepted root: every
-//    sphere not registered in a visited cell has all its candidate points more than eps beyond
-//    that boundary, so its root is larger;
-//  * rays that start FARTHER away (a bounce off the ground plane hundreds of units out: E grows
-//    with |oc|^2) are clipped against the box of the gridded CENTRES inflated by their own
-//    sqrt(rmax^2 + E(ray)): if the line misses it no gridded sphere can be accepted, otherwise
-//    (a far ray skimming the scene, < 0.01 % of the rays) the whole wave takes the screened
-//    brute-force loop above for this one segment.  NaN / zero / huge rays go the same way.
-// Tested bit for bit against the exact loop on full frames of every scene, both precisions, and
-// on random scenes (tests/test_gpu_parity.py).
-// =====================================================================================
-template <class T>
-__device__ __forceinline__ void direct_trip(const T* g, const int* ids, int s, const LoopRay<T>& r, T& closest, int& hit, FastDiv<T> fd) {
-    const Trip<T> t = trip_discriminants(g, s, r);
-    // no common guard: some lane has a candidate on the direct list (the ground) in nearly every trip
-    if (t.d0 >= (T)0) finish_sphere_test<T, true>(ids[s + 0], t.h0, t.d0, r.a, closest, hit, fd);
-    if (t.d1 >= (T)0) finish_sphere_test<T, true>(ids[s + 1], t.h1, t.d1, r.a, closest, hit, fd);
-    if (t.d2 >= (T)0) finish_sphere_test<T, true>(ids[s + 2], t.h2, t.d2, r.a, closest, hit, fd);
-    if (t.d3 >= (T)0) finish_sphere_test<T, true>(ids[s + 3], t.h3, t.d3, r.a, closest, hit, fd);
-}
-
-// {cx, cy, cz, r*r} of sphere i for the per-lane gathers of the walk: fp32 from the AoS copy in the
-// grid blob (one ds_read_b128), fp64 from geom_a, which is AoS already.
-__device__ __forceinline__ void load_sphere(const float* aos, int i, float& cx, float& cy, float& cz, float& r2) {
-    const v4f c = reinterpret_cast<const v4f*>(aos)[i];
-    cx = c.x; cy = c.y; cz = c.z; r2 = c.w;
-}
-__device__ __forceinline__ void load_sphere(const double* aos, int i, double& cx, double& cy, double& cz, double& r2) {
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    const v2d lo = reinterpret_cast<const v2d*>(aos)[2 * i], hi = reinterpret_cast<const v2d*>(aos)[2 * i + 1];
-    cx = lo.x; cy = lo.y; cz = hi.x; r2 = hi.y;
-}
-
-// The (up to) four spheres of one cell, hittable.h:42-57 each, for this lane's own ray.
-template <class T>
-__device__ __forceinline__ void cell_tests(const T* aos, unsigned rec_lo, unsigned rec_hi, V3<T> O, V3<T> D, T a, T& closest, int& hit, FastDiv<T> fd) {
-    const int id[4] = {(int)(rec_lo & 0xffffu), (int)(rec_lo >> 16), (int)(rec_hi & 0xffffu), (int)(rec_hi >> 16)};
-    T h[4], disc[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        T cx, cy, cz, r2;
-        load_sphere(aos, id[k], cx, cy, cz, r2);
-        const T ocx = cx - O.x, ocy = cy - O.y, ocz = cz - O.z;                         // :42
-        h[k] = RT_FMA(D.z, ocz, RT_FMA(D.y, ocy, D.x * ocx));                            // :44
-        const T c = RT_FMA(ocz, ocz, RT_FMA(ocy, ocy, ocx * ocx)) - r2;                  // :45
-        disc[k] = RT_FMA(h[k], h[k], -(a * c));                                          // :47
-    }
-    const T m = Real<T>::fmax(Real<T>::fmax(disc[0], disc[1]), Real<T>::fmax(disc[2], disc[3]));
-    if (m >= (T)0) {                                                                    // :48 for any of the four
-        PATH_STAT(PS_EXACT_BLOCK);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (disc[k] >= (T)0) finish_sphere_test<T, true>(id[k], h[k], disc[k], a, closest, hit, fd);
-    }
-}
-
-// Clip of o + t d against [lo, hi] on one axis, folded into [t0, t1].  Raw reciprocal: see eps above.
-// Returns the raw reciprocal of d it used (0 for a parallel ray): the walk steps with the same values.
-__device__ __forceinline__ float clip_axis(float o, float d, float lo, float hi, float& t0, float& t1) {
-    if (__builtin_fabsf(d) < 1e-30f) {
-        if (!(o >= lo && o <= hi)) t1 = -__builtin_huge_valf();
-        return 0.0f;
-    }
-    const float inv = __builtin_amdgcn_rcpf(d);
-    const float ta = (lo - o) * inv, tb = (hi - o) * inv;
-    t0 = __builtin_fmaxf(t0, __builtin_fminf(ta, tb));
-    t1 = __builtin_fminf(t1, __builtin_fmaxf(ta, tb));
-    return inv;
-}
-
-template <class T>
-__device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T* lds_exact, const float* lds_screen,
-                                               V3<T> O, V3<T> D, T a, T& closest, int& hit) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const auto& g = grid_of(p);
-    REGION_BEGIN(setup);
-    // ---- which rays the registration margins cover
-    const float fx = (float)(O.x - p.ctr_x), fy = (float)(O.y - p.ctr_y), fz = (float)(O.z - p.ctr_z);
-    const float k2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
-    const float af = (float)a;
-    const bool sane = af > 1e-30f && af < 1e30f && k2 < 1e30f;        // false for NaN as well
-    const bool near = sane && k2 <= g.far2;
-    const float ox = (float)O.x - g.x0, oy = (float)O.y, oz = (float)O.z - g.z0;
-    const float dx = (float)D.x, dy = (float)D.y, dz = (float)D.z;
-    float t0 = 0.0f, t1 = __builtin_huge_valf();
-    float xlo = 0.0f, xhi = (float)g.nx * g.cell, zlo = 0.0f, zhi = (float)g.nz * g.cell, ylo = g.ylo, yhi = g.yhi;
-    if (__builtin_amdgcn_ballot_w64(!near) != 0) {
-        // a far ray: can any gridded sphere pass the reference's discriminant test at all?  Only if the
-        // line comes within rho = sqrt(rmax^2 + E) of a centre, E = 18u((|O'| + Cmax)^2 + rmax^2)
-        // (2^-20 instead of 18 * 2^-24 and the 1.001 cover the raw square roots).
-        const float reach = fast_sqrt(k2) * 1.001f + g.cmax;
-        const float E = 9.5367431640625e-07f * __builtin_fmaf(reach, reach, g.rmax2);
-        const float rho = fast_sqrt(g.rmax2 + E) * 1.001f;
-        if (!near) {
-            xlo = g.core_lo[0] - g.x0 - rho; xhi = g.core_hi[0] - g.x0 + rho;
-            ylo = g.core_lo[1] - rho;        yhi = g.core_hi[1] + rho;
-            zlo = g.core_lo[2] - g.z0 - rho; zhi = g.core_hi[2] - g.z0 + rho;
-        }
-    }
-    clip_axis(oy, dy, ylo, yhi, t0, t1);
-    const float inv_dx = clip_axis(ox, dx, xlo, xhi, t0, t1);
-    const float inv_dz = clip_axis(oz, dz, zlo, zhi, t0, t1);
-    const bool crosses = !sane || t0 <= t1;
-    REGION_END(setup, RG_GRID_SETUP);
-    if (__builtin_amdgcn_ballot_w64(!near && crosses) != 0) {
-        REGION_BEGIN(fallback);
-        hit_world_screened<T>(p, lds_exact, lds_screen, O, D, a, closest, hit);   // exact for every lane of the wave
-        REGION_END(fallback, RG_GRID_FALLBACK);
-        return;
-    }
-    // ---- one reciprocal for every quotient of this segment (FastDiv above ieee_roots)
-    FastDiv<T> fd = {(T)0, false};
-    if (p.range_flags & 2) {
-        fd.on = __builtin_amdgcn_ballot_w64(!(a >= (T)0x1p-40 && a <= (T)0x1p40)) == 0;
-        fd.ra = refined_reciprocal(a);
-    }
-    REGION_BEGIN(direct);
-#ifdef RTIOW_PROBE_DIRECT
-    {
-        V3<T> o2 = O, d2 = D; rt_opaque(o2); rt_opaque(d2); T c2 = __builtin_huge_val(); int h2 = -1;
-        const T* dg = reinterpret_cast<const T*>(smem_raw + g.direct_offset);
-        const int* ids = reinterpret_cast<const int*>(smem_raw + g.direct_ids_offset);
-        const LoopRay<T> r = make_loop_ray(o2.x, o2.y, o2.z, d2.x, d2.y, d2.z, a);
-        for (int s = 0; s < g.n_direct_padded; s += 4) direct_trip<T>(dg, ids, s, r, c2, h2, fd);
-        RT_KEEP1(c2); RT_KEEP1(h2);
-    }
-#endif
-    // The direct list and the walk, instantiated for both values of fd.on: ONE scalar branch per segment picks the
-    // copy, inside it every quotient's form is fixed at compile time (a branch at each of the eight finishing
-    // sites cost 6 % more scalar instructions).
-    auto direct_list_and_walk = [&](auto fast_tag) __attribute__((always_inline)) {
-        const FastDiv<T> fdc = {fd.ra, decltype(fast_tag)::value};
-        // ---- the direct list: packed trips, every ray
-        {
-            const T* dg = reinterpret_cast<const T*>(smem_raw + g.direct_offset);
-            const int* ids = reinterpret_cast<const int*>(smem_raw + g.direct_ids_offset);
-            const LoopRay<T> r = make_loop_ray(O.x, O.y, O.z, D.x, D.y, D.z, a);
-#ifndef RTIOW_ABLATE_DIRECT
-            for (int s = 0; s < g.n_direct_padded; s += 4) direct_trip<T>(dg, ids, s, r, closest, hit, fdc);
-#endif
-        }
-        REGION_END(direct, RG_GRID_DIRECT);
-        // ---- the walk
-        REGION_BEGIN(walk);
-        bool walking = near && crosses;
-#ifdef RTIOW_ABLATE_WALK
-        walking = false;
-#endif
-        if (__builtin_amdgcn_ballot_w64(walking) == 0) { REGION_END(walk, RG_GRID_WALK); return; }
-        const T* aos = sizeof(T) == 4 ? reinterpret_cast<const T*>(smem_raw + g.aos_offset) : lds_exact;
-        const uint2* cells = reinterpret_cast<const uint2*>(smem_raw + g.cells_offset);
-        const float px = __builtin_fmaf(t0, dx, ox), pz = __builtin_fmaf(t0, dz, oz);
-        int cx = (int)__builtin_floorf(px * g.inv_cell), cz = (int)__builtin_floorf(pz * g.inv_cell);
-        cx = cx < 0 ? 0 : (cx >= g.nx ? g.nx - 1 : cx);
-        cz = cz < 0 ? 0 : (cz >= g.nz ? g.nz - 1 : cz);
-        const bool step_x = __builtin_fabsf(dx) >= 1e-30f, step_z = __builtin_fabsf(dz) >= 1e-30f;
-        const int sx = dx > 0.0f ? 1 : -1, sz = dz > 0.0f ? 1 : -1;
-        while (__builtin_amdgcn_ballot_w64(walking) != 0) {
-            if (walking) {
-                PATH_STAT(PS_GRID_STEP);
-                const uint2 rec = cells[cz * g.nx + cx];
-                if (rec.x != 0xffffffffu) cell_tests<T>(aos, rec.x, rec.y, O, D, a, closest, hit, fdc);
-                // the parameter at which the ray leaves this cell, per axis
-                const float bx = (float)(cx + (sx > 0 ? 1 : 0)) * g.cell, bz = (float)(cz + (sz > 0 ? 1 : 0)) * g.cell;
-                const float tx = step_x ? (bx - ox) * inv_dx : __builtin_huge_valf();
-                const float tz = step_z ? (bz - oz) * inv_dz : __builtin_huge_valf();
-                const float tnext = __builtin_fminf(tx, tz);
-                const float tend = __builtin_fminf(t1, (float)closest);           // (float) rounds to nearest: covered by eps
-                if (tnext >= tend) walking = false;                               // leaves the slab / the grid, or a nearer hit is known
-                else {
-                    if (tx <= tz) cx += sx; else cz += sz;
-                    if ((unsigned)cx >= (unsigned)g.nx || (unsigned)cz >= (unsigned)g.nz) walking = false;
-                }
-            }
-        }
-        REGION_END(walk, RG_GRID_WALK);
-    };
-    if (fd.on) direct_list_and_walk(std::true_type{});
-    else direct_list_and_walk(std::false_type{});
-}
-
-template <class T, int SRC>
-__device__ __forceinline__ void hit_world(const RenderParams<T>& p, const T* lds_geom, V3<T> O, V3<T> D, T a, T& closest, int& hit) {
-    hit_world_direct<T, SRC>(p, lds_geom, O, D, a, closest, hit);
-}
-template <>
-__device__ __forceinline__ void hit_world<double, RTIOW_SCENE_LDS>(const RenderParams<double>& p, const double* lds_geom, V3<double> O, V3<double> D,
-                                                                   double a, double& closest, int& hit) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    if (p.use_grid) {
-        hit_world_grid<double>(p, lds_geom, reinterpret_cast<const float*>(smem_raw + p.screen_offset), O, D, a, closest, hit);
-    } else if (p.use_screen) {
-        hit_world_screened<double>(p, lds_geom, reinterpret_cast<const float*>(smem_raw + p.screen_offset), O, D, a, closest, hit);
-    } else {
-        hit_world_direct<double, RTIOW_SCENE_LDS>(p, lds_geom, O, D, a, closest, hit);
-    }
-}
-template <>
-__device__ __forceinline__ void hit_world<float, RTIOW_SCENE_LDS>(const RenderParams<float>& p, const float* lds_geom, V3<float> O, V3<float> D,
-                                                                  float a, float& closest, int& hit) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    if (p.use_grid) {
-        hit_world_grid<float>(p, lds_geom, reinterpret_cast<const float*>(smem_raw + p.screen_offset), O, D, a, closest, hit);
-    } else if (p.use_screen) {
-        hit_world_screened<float>(p, lds_geom, reinterpret_cast<const float*>(smem_raw + p.screen_offset), O, D, a, closest, hit);
-    } else {
-        hit_world_direct<float, RTIOW_SCENE_LDS>(p, lds_geom, O, D, a, closest, hit);
-    }
-}
-
-// Per-lane path state of the flattened samples x bounces loop.
-template <class T> struct PathState {
-    V3<T> O, D, atten, acc;
-    T sky_uy;
-    int sample, depth;
-    Rng rs;
-};
-
-// Everything after hit_world in one trip of the loop at camera.h:84: sky on a miss
-// (camera.h:120-124), else hit record + scatter (camera.h:88-117).  Returns true when the
-// path ended; `col` is then its colour.
-template <class T>
-__device__ __forceinline__ bool shade_step(const RenderParams<T>& p, const T* lds_shade, PathState<T>& st, T closest, int hit, V3<T>& col) {
-    col = {0, 0, 0};
-    const V3<T> O = st.O, D = st.D;
-    if (hit < 0) {
-        PATH_STAT(PS_SKY);
-        // ------------ sky, from the PRIMARY ray (camera.h:120-124)
-        const double a_sky = 0.5 * ((double)st.sky_uy + 1.0);
-        const T w1 = (T)(1.0 - a_sky), w2 = (T)a_sky;
-        const V3<T> sky = {RT_FMA(w2, (T)0.5, w1), RT_FMA(w2, (T)0.7, w1), RT_FMA(w2, (T)1.0, w1)};
-        col = {st.atten.x * sky.x, st.atten.y * sky.y, st.atten.z * sky.z};
-        return true;
-    }
-    // ------------ complete the hit record (hittable.h:59-63, :21-26)
-    // one 12-word record per sphere; LDS copy when it fits (no global-load latency on the
-    // critical path of the drain tail), else through L1/L2
-    PATH_STAT(PS_SHADE_HIT);
-    T rec[12];
-    if (p.shade_in_lds) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) rec[k] = lds_shade[12 * hit + k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) rec[k] = p.shade_tbl[12 * (size_t)hit + k];
-    }
-    const V3<T> C = {rec[0], rec[1], rec[2]};
-    const T inv_r = rec[3];
-    const V3<T> P = madd3(closest, D, O);
-    const V3<T> outward = {inv_r * (P.x - C.x), inv_r * (P.y - C.y), inv_r * (P.z - C.z)};
-    const bool front = dot3(D, outward) < (T)0;
-    const V3<T> nrm = front ? outward : V3<T>{-outward.x, -outward.y, -outward.z};
-    const int mtype = (int)rec[10];
-    V3<T> nd;
-    V3<T> att = {rec[4], rec[5], rec[6]};
-    bool ok = true;
-    if (mtype == RTIOW_DIELECTRIC) {                                     // material.h:68-89
-        PATH_STAT(PS_DIELECTRIC);
-        att = {1, 1, 1};
-        const T ri = front ? rec[9] : rec[8];
-        const V3<T> ud = unit3(D);
-        const T cos_theta = Real<T>::fmin(-dot3(ud, nrm), (T)1);
-        const T sin_theta = sqrt_wave_checked(RT_FMA(-cos_theta, cos_theta, (T)1));
-        bool reflect_it = ri * sin_theta > (T)1;
-        if (!reflect_it) {
-            const T r0 = front ? rec[4] : rec[5];                       // material.h:62-66: ((1 - ri) / (1 + ri))^2, computed by upload_scene in T
-            const float x = (float)((T)1 - cos_theta);
-            const float x2 = x * x;
-            const float p5 = (x2 * x2) * x;                              // powf(x,5), see DESIGN.md
-            PATH_STAT(PS_SCHLICK_DRAW);
-            const T refl = RT_FMA((T)1 - r0, (T)p5, r0);
-            reflect_it = refl > Real<T>::uniform(st.rs);
-        }
-        if (reflect_it) {
-            nd = reflect3(ud, nrm);
-        } else {                                                         // vec3.h:133-138
-            const V3<T> perp = scale3(ri, madd3(cos_theta, nrm, ud));
-            const T k = -sqrt_wave_checked(Real<T>::fabs((T)1 - dot3(perp, perp)));
-            nd = madd3(k, nrm, perp);
-        }
-    } else {
-#ifdef RTIOW_PROBE_RUV
-        { Rng c = st.rs; rt_opaque(c); V3<T> r2 = random_unit_vector<T>(c); RT_KEEP1(r2.x); RT_KEEP1(r2.y); RT_KEEP1(r2.z); RT_KEEP1(c.v4); }
-#endif
-        const V3<T> ruv = random_unit_vector<T>(st.rs);
-        if (mtype == RTIOW_LAMBERTIAN) {                                 // material.h:38-49
-            nd = {nrm.x + ruv.x, nrm.y + ruv.y, nrm.z + ruv.z};
-            const T e = Real<T>::near_zero;
-            if (Real<T>::fabs(nd.x) < e && Real<T>::fabs(nd.y) < e && Real<T>::fabs(nd.z) < e) nd = nrm;
-        } else {                                                         // material.h:51-59
-            PATH_STAT(PS_METAL);
-            const V3<T> ur = unit3(reflect3(D, nrm));
-            nd = madd3(rec[7], ruv, ur);
-            ok = dot3(nd, nrm) > (T)0;
-        }
-    }
-    if (!ok) return true;                                                // camera.h:117
-    st.atten = {st.atten.x * att.x, st.atten.y * att.y, st.atten.z * att.z};   // camera.h:110-115
-    st.O = P; st.D = nd;
-    ++st.depth;
-    return false;
-}
-
-// One path segment (one trip of the loop at camera.h:84) done by the lane alone.
-template <class T, int SRC>
-__device__ __forceinline__ bool segment_step(const RenderParams<T>& p, const T* lds_geom, const T* lds_shade, PathState<T>& st, V3<T>& col) {
-    if (st.depth >= p.B) { col = {0, 0, 0}; return true; }   // camera.h:127 (also B <= 0)
-    // ---------------- hit_world (hittable.h:80-98), nearest (t, index) only
-    T closest = __builtin_huge_val();
-    int hit = -1;
-    const T a = dot3(st.D, st.D);                 // hittable.h:43, ray-invariant
-    hit_world<T, SRC>(p, lds_geom, st.O, st.D, a, closest, hit);
-    return shade_step<T>(p, lds_shade, st, closest, hit, col);
-}
-
-// ---- the last stage of the drain: ONE ray left in a full wave.  The ray is broadcast with
-// v_readlane (no LDS round trip), every lane takes one 4-sphere trip, and the 64 partial hits are
-// reduced as one 64-bit key {t bits, index} -- t > 0 or +inf, so the IEEE bits order like the
-// values and the key minimum is the lexicographic (t, index) minimum of the exact loop -- with DPP
-// row operations (register-to-register) plus four readlanes, instead of 14 ds_bpermute round trips.
-template <int CTRL> __device__ __forceinline__ unsigned dpp_mov(unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
-}
-template <int CTRL> __device__ __forceinline__ void key_min_step(unsigned& hi, unsigned& lo) {
-    const unsigned ohi = dpp_mov<CTRL>(hi), olo = dpp_mov<CTRL>(lo);
-    const bool take = (ohi < hi) || (ohi == hi && olo < lo);
-    hi = take ? ohi : hi;
-    lo = take ? olo : lo;
-}
-__device__ __forceinline__ unsigned long long wave_min_key(unsigned hi, unsigned lo) {
-    key_min_step<0xB1>(hi, lo);      // quad_perm [1,0,3,2]  : lane ^ 1
-    key_min_step<0x4E>(hi, lo);      // quad_perm [2,3,0,1]  : lane ^ 2
-    key_min_step<0x141>(hi, lo);     // row_half_mirror      : across the quads of a half row
-    key_min_step<0x140>(hi, lo);     // row_mirror           : across the half rows -> every lane of a 16-lane row holds the row minimum
-    unsigned long long best = ~0ull;
-#pragma unroll
-    for (int row = 0; row < 4; ++row) {
-        const unsigned long long k = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, row * 16) << 32) |
-                                     (unsigned)__builtin_amdgcn_readlane((int)lo, row * 16);
-        best = k < best ? k : best;
-    }
-    return best;
-}
-
-template <int SRC>
-__device__ __forceinline__ void hit_world_solo(const RenderParams<float>& p, const float* lds_geom, int owner, bool is_owner,
-                                               V3<float> O, V3<float> D, float a, float& closest, int& hit) {
-    auto bcast = [owner](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), owner)); };
-    const float ox = bcast(O.x), oy = bcast(O.y), oz = bcast(O.z);
-    const float dx = bcast(D.x), dy = bcast(D.y), dz = bcast(D.z);
-    const float ra = bcast(a);
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const float* gm = (SRC == RTIOW_SCENE_LDS) ? lds_geom : p.geom_a;
-    const LoopRay<float> r = make_loop_ray(ox, oy, oz, dx, dy, dz, ra);
-    float best = __builtin_huge_valf();
-    int best_idx = -1;
-    for (int s = lane * 4; s < p.n_padded; s += 256) sphere_trip<float>(gm, s, r, best, best_idx);
-    // Few lanes hold a hit at all (the ray meets a handful of spheres): walk those lanes with readlanes -- a short
-    // scalar loop -- instead of the 64-lane DPP minimum, which is ~60 dependent instructions of pure latency here.
-    const unsigned long long holders = __builtin_amdgcn_ballot_w64(best_idx >= 0);
-    unsigned long long k = 0x7f800000ffffffffull;   // {+inf, -1}: no hit
-    if (__builtin_popcountll(holders) <= 6) {
-        unsigned long long m = holders;
-        while (m != 0) {
-            const int l = (int)__builtin_ctzll(m);
-            m &= m - 1;
-            const unsigned long long kl = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(best), l) << 32) |
-                                          (unsigned)__builtin_amdgcn_readlane(best_idx, l);
-            k = kl < k ? kl : k;
-        }
-    } else k = wave_min_key(__float_as_uint(best), (unsigned)best_idx);
-    if (is_owner) { closest = __uint_as_float((unsigned)(k >> 32)); hit = (int)(unsigned)k; }
-}
-
-template <int SRC>
-__device__ __forceinline__ void coop_solo(const RenderParams<float>& p, const float* g, int owner, bool is_owner, V3<float> O, V3<float> D, float a, float& closest, int& hit) {
-    hit_world_solo<SRC>(p, g, owner, is_owner, O, D, a, closest, hit);
-}
-template <int SRC>
-__device__ __forceinline__ void coop_solo(const RenderParams<double>&, const double*, int, bool, V3<double>, V3<double>, double, double&, int&) {}
-
-// ---- cooperative hit_world for the drain tail of the persistent kernel.
-// When the work pool is empty and n <= 32 lanes of a wave still carry a path, the wave's
-// idle lanes help: the n rays are published in LDS, each ray is served by a group of
-// g = 2^floor(log2(lanes/n)) lanes that split the 4-sphere trips of hit_world_direct between
-// them, and the partial nearest hits are reduced with xor-shuffles.  The nearest hit of
-// the reference loop is the lexicographic minimum of (t, index) over the spheres -- a
-// sphere's accepted root does not depend on closest_so_far except through `root < closest`
-// (hittable.h:53-57) -- so any partition + min-reduction returns exactly what the
-// sequential loop returns.  This cuts the latency of one segment from N sphere tests to
-// N/g, which is what bounds the kernel once only the long glass paths are left.
-template <class T> struct CoopSlot { T ox, oy, oz, a, dx, dy, dz, pad; };
-
-// the value lane l holds, as a wave-uniform scalar
-__device__ __forceinline__ float lane_value(float v, int l) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); }
-__device__ __forceinline__ double lane_value(double v, int l) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
-// log2 of the lanes each of n rays gets when a wave of `lanes` lanes splits their sphere loops: floor(log2(lanes)) -
-// ceil(log2(n)) -- exact for the 64-lane waves of the dynamic schedules, never too large otherwise (two count-
-// leading-zeros instead of a loop: this runs every trip of the drain, where a lone ray's trip is all latency).
-__device__ __forceinline__ int lanes_per_ray_log2(int n, int lanes) {
-    const int up = n > 1 ? 32 - __builtin_clz((unsigned)(n - 1)) : 0;
-    const int lg = (31 - __builtin_clz((unsigned)lanes)) - up;
-    return lg > 0 ? lg : 0;
-}
-
-template <class T, int SRC>
-__device__ __forceinline__ void hit_world_coop(const RenderParams<T>& p, const T* lds_geom, CoopSlot<T>* slots,
-                                               bool alive, unsigned long long alive_mask, int n_alive, int wave_lanes,
-                                               V3<T> O, V3<T> D, T a, T& closest, int& hit) {
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(alive_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)alive_mask, 0u));
-    const int lg = lanes_per_ray_log2(n_alive, wave_lanes);   // g = 2^lg lanes per ray, n_alive * g <= lanes of this wave
-    const int g = 1 << lg;
-    if (alive) slots[rank] = {O.x, O.y, O.z, a, D.x, D.y, D.z, (T)0};
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int group = lane >> lg, sub = lane & (g - 1);
-    T best = __builtin_huge_val();
-    int best_idx = -1;
-    if (group < n_alive) {
-        const CoopSlot<T> cs = slots[group];
-        const LoopRay<T> r = make_loop_ray(cs.ox, cs.oy, cs.oz, cs.dx, cs.dy, cs.dz, cs.a);
-        const T* gm = (SRC == RTIOW_SCENE_LDS) ? lds_geom : p.geom_a;
-        for (int s = sub * 4; s < p.n_padded; s += g * 4) sphere_trip<T>(gm, s, r, best, best_idx);
-    }
-    if (n_alive <= 4) {
-        // Few rays, wide groups: the xor-shuffle reduction below is log2(g) dependent LDS round trips (five for two
-        // rays; fp64 has no single-ray path, so six for one).  A ray meets a handful of spheres, so few lanes of its
-        // group hold a hit: walk those lanes with readlanes, ray by ray, and hand the result to the ray's owner --
-        // all scalar, no LDS.
-        const unsigned long long holders = __builtin_amdgcn_ballot_w64(best_idx >= 0);
-        const unsigned long long group_lanes = g >= 64 ? ~0ull : ((1ull << g) - 1);
-        for (int j = 0; j < n_alive; ++j) {
-            unsigned long long m = holders & (group_lanes << (j << lg));
-            T bt = __builtin_huge_val();
-            int bi = -1;
-            while (m != 0) {
-                const int l = (int)__builtin_ctzll(m);
-                m &= m - 1;
-                const T tl = lane_value(best, l);
-                const int il = __builtin_amdgcn_readlane(best_idx, l);
-                const bool take = (tl < bt) || (tl == bt && (unsigned)il < (unsigned)bi);
-                bt = take ? tl : bt;
-                bi = take ? il : bi;
-            }
-            if (alive && rank == j) { closest = bt; hit = bi; }
-        }
-        return;
-    }
-    // lexicographic (t, index) minimum over the g lanes of the group
-    for (int off = 1; off < g; off <<= 1) {
-        const T ot = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(best_idx, off, 64);
-        const bool take = (ot < best) || (ot == best && (unsigned)oi < (unsigned)best_idx);
-        best = take ? ot : best;
-        best_idx = take ? oi : best_idx;
-    }
-    // owner of slot k reads lane k*g
-    const T rt = __shfl(best, rank << lg, 64);
-    const int ri = __shfl(best_idx, rank << lg, 64);
-    if (alive) { closest = rt; hit = ri; }
-}
-
-// camera.h:167-171, color.h:10-13.  The RNG state is deliberately not written back.
-template <class T, class COLD>
-__device__ __forceinline__ void store_pixel(const COLD& c, size_t lp, V3<T> acc) {
-    acc = scale3((T)c.pixel_samples_scale, acc);
-    T* o = c.fb + lp * 3;
-    o[0] = acc.x > (T)0 ? Real<T>::sqrt(acc.x) : (T)0;
-    o[1] = acc.y > (T)0 ? Real<T>::sqrt(acc.y) : (T)0;
-    o[2] = acc.z > (T)0 ? Real<T>::sqrt(acc.z) : (T)0;
-}
-
-template <class T, int SRC>
-__device__ __forceinline__ T* stage_scene(const RenderParams<T>& p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* lds_geom = reinterpret_cast<T*>(smem_raw);
-    if (SRC == RTIOW_SCENE_LDS || p.shade_in_lds) {
-        // Stage the loop table {cx,cy,cz,r^2} (and the shade records when they fit): coalesced
-        // global reads, one pass.
-        if (SRC == RTIOW_SCENE_LDS) {
-            for (int k = threadIdx.x; k < p.n_padded * 4; k += blockDim.x) lds_geom[k] = p.geom_a[k];
-            if (p.use_screen) {
-                float* lds_screen = reinterpret_cast<float*>(smem_raw + p.screen_offset);   // fp32 for both precisions
-                for (int k = threadIdx.x; k < p.n_padded * 4; k += blockDim.x) lds_screen[k] = p.geom_s[k];
-            }
-        }
-        if (p.shade_in_lds) {
-            T* lds_shade = reinterpret_cast<T*>(smem_raw + p.shade_offset);
-            for (int k = threadIdx.x; k < p.n * 12; k += blockDim.x) lds_shade[k] = p.shade_tbl[k];
-        }
-        if (SRC == RTIOW_SCENE_LDS && p.use_grid) {
-            uint32_t* dst = reinterpret_cast<uint32_t*>(smem_raw + p.grid.cells_offset);
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(p.grid.blob);
-            for (int k = threadIdx.x; k < p.grid.blob_bytes / 4; k += blockDim.x) dst[k] = src[k];
-        }
-        __syncthreads();
-    }
-    return lds_geom;
-}
-
-__device__ __forceinline__ int global_row(int jl, int strip_rows, int nranks, int rank) {
-    return ((jl / strip_rows) * nranks + rank) * strip_rows + (jl % strip_rows);
-}
-
-// End of a pixel in one launch: the final phase writes the pixel
-// (camera.h:167-171); the prepass of the sorted schedule parks the exact state instead.
-// Per-pixel hand-over record, read and written as 16-byte vectors: fp32 48 bytes, fp64 64 bytes.
-template <class T> struct MidState;
-template <> struct alignas(16) MidState<float>  { uint32_t v[5], d; float acc[3]; uint32_t pad[3]; };
-template <> struct alignas(16) MidState<double> { uint32_t v[5], d; uint32_t pad[2]; double acc[3]; uint32_t pad2[2]; };
-static_assert(sizeof(MidState<float>) == 48 && sizeof(MidState<double>) == 64, "hand-over record layout");
-
-template <class T>
-__device__ __forceinline__ void park_state(unsigned char* base, size_t lp, const PathState<T>& st) {
-    MidState<T> m;
-    m.v[0] = st.rs.v0; m.v[1] = st.rs.v1; m.v[2] = st.rs.v2; m.v[3] = st.rs.v3; m.v[4] = st.rs.v4; m.d = st.rs.d;
-    m.acc[0] = st.acc.x; m.acc[1] = st.acc.y; m.acc[2] = st.acc.z;
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    const u4* src = reinterpret_cast<const u4*>(&m);
-    u4* dst = reinterpret_cast<u4*>(base + lp * sizeof(MidState<T>));
-#pragma unroll
-    for (int k = 0; k < (int)(sizeof(MidState<T>) / 16); ++k) dst[k] = src[k];
-}
-template <class T>
-__device__ __forceinline__ void unpark_state(const unsigned char* base, size_t lp, PathState<T>& st) {
-    MidState<T> m;
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    const u4* src = reinterpret_cast<const u4*>(base + lp * sizeof(MidState<T>));
-    u4* dst = reinterpret_cast<u4*>(&m);
-#pragma unroll
-    for (int k = 0; k < (int)(sizeof(MidState<T>) / 16); ++k) dst[k] = src[k];
-    st.rs.v0 = m.v[0]; st.rs.v1 = m.v[1]; st.rs.v2 = m.v[2]; st.rs.v3 = m.v[3]; st.rs.v4 = m.v[4]; st.rs.d = m.d;
-    st.acc = {m.acc[0], m.acc[1], m.acc[2]};
-}
-
-template <class T, class COLD>
-__device__ __forceinline__ void finish_pixel(const COLD& c, size_t lp, const PathState<T>& st, unsigned int cost) {
-    if (c.mid_out) {
-        park_state<T>(c.mid_out, lp, st);
-        c.cost_out[lp] = cost;
-    } else {
-        store_pixel<T>(c, lp, st.acc);
-    }
-}
-
-// ---- SCHED_STATIC: the reference's launch geometry, one lane = one pixel of a T x T block
-// (camera.h:131-134), with the flattened sample/bounce loop.
-template <class T, int SRC, bool COUNT>
-__global__ void __launch_bounds__(1024)
-render_kernel(const RenderParams<T> p) {
-    const T* lds_geom = stage_scene<T, SRC>(p);
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const T* lds_shade = reinterpret_cast<const T*>(smem_raw + p.shade_offset);
-    const ColdParams<T>& c = p.cold;
-    const int tid = threadIdx.x;
-    int tx, ty;
-    if (c.wave_tiles) {
-        const int wave = tid >> 6, lane = tid & 63;
-        const int tiles_x = c.bx >> 3;
-        tx = (wave % tiles_x) * 8 + (lane & 7);
-        ty = (wave / tiles_x) * 8 + (lane >> 3);
-    } else {
-        tx = tid % c.bx;                        // CUDA's threadIdx.x
-        ty = tid / c.bx;                        // CUDA's threadIdx.y
-    }
-    const int i = blockIdx.x * c.bx + tx;
-    const int jl = blockIdx.y * c.by + ty;      // local row
-    if (i >= c.W || jl >= c.local_rows) return; // camera.h:133
-    const int j = global_row(jl, c.strip_rows, c.nranks, c.rank);
-    const size_t lp = (size_t)jl * c.W + i;
-
-    const size_t npix = (size_t)c.W * c.local_rows;
-    PathState<T> st;
-    st.rs.v0 = c.rng_in[0 * npix + lp]; st.rs.v1 = c.rng_in[1 * npix + lp]; st.rs.v2 = c.rng_in[2 * npix + lp];   // camera.h:136
-    st.rs.v3 = c.rng_in[3 * npix + lp]; st.rs.v4 = c.rng_in[4 * npix + lp]; st.rs.d = c.rng_in[5 * npix + lp];
-    st.acc = {0, 0, 0};
-    st.sample = c.s_begin; st.depth = 0;          // this launch renders samples [s_begin, s_end)
-    unsigned int nseg = 0, cost = 0;
-    const int S = p.s_end;
-    bool fresh = true;                            // the lane needs a primary ray (camera.h:141-155)
-
-    while (st.sample < S) {
-        PATH_STAT(PS_ITERATION);
-        if (fresh) { gen_primary(p, i, j, st.rs, st.O, st.D, st.sky_uy); st.atten = {1, 1, 1}; fresh = false; }
-        V3<T> col;
-        if (st.depth < p.B) { ++cost; if (COUNT) ++nseg; }
-        if (segment_step<T, SRC>(p, lds_geom, lds_shade, st, col)) {
-            st.acc = {st.acc.x + col.x, st.acc.y + col.y, st.acc.z + col.z};       // camera.h:160
-            ++st.sample;
-            st.depth = 0;
-            fresh = true;
-        }
-    }
-    if (COUNT) { atomicAdd(c.seg_counter, (unsigned long long)nseg); atomicMax(c.seg_counter + 2, (unsigned long long)cost); }
-    finish_pixel<T>(c, lp, st, cost);
-}
-
-// ---- SCHED_PERSISTENT: lanes are not bound to pixels.  Each wave keeps a pool of 64 pixel
-// slots (one 8x8 tile) taken from a global counter; a lane that finishes its pixel takes the
-// next slot at once (ballot + mbcnt hand-out, no memory traffic), so no lane waits for the
-// longest path of a tile-mate and the grid is balanced across CUs by construction.  Slots run
-// tile-major from the BOTTOM of the image up (ground and spheres first, cheap sky last) to
-// keep the drain tail short.  Per-pixel work and RNG streams are unchanged => same image.
-constexpr int POOL = 64;
-// Longest share of the brute-force sphere loop (trips of four spheres) for which the drain still splits it
-// among idle lanes instead of walking the grid (persistent_body).
-#ifndef RTIOW_COOP_MAX_TRIPS
-#define RTIOW_COOP_MAX_TRIPS 6
-#endif
-
-template <class T, int SRC, bool COUNT, bool SOLO = false>
-__device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
-    const T* lds_geom = stage_scene<T, SRC>(p);
-    // per-wave scratch for hit_world_coop, behind the staged tables
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const T* lds_shade = reinterpret_cast<const T*>(smem_raw + p.shade_offset);
-    CoopSlot<T>* coop_slots = reinterpret_cast<CoopSlot<T>*>(smem_raw + p.coop_offset) + (threadIdx.x >> 6) * 64;
-    const int S = p.s_end;                       // this launch renders samples [cold.s_begin, p.s_end)
-
-    PathState<T> st;
-    st.acc = {0, 0, 0};
-    st.sample = 0; st.depth = 0;
-    unsigned int cost = 0;                       // segments of the lane's current pixel in this launch
-    bool alive = false, fresh = false;
-    int i = 0, j = 0;
-    size_t lp = 0;
-    unsigned int nseg = 0;
-    int pool_next = 0, pool_end = 0;             // wave-uniform
-    bool exhausted = false;                      // wave-uniform
-    // p.first_pools: wave w takes pool w first and the counter starts behind them.  Workgroups are
-    // dispatched in blockIdx order and the SIMD arbiter favours older waves, so this puts the
-    // heaviest block of the cost-sorted order on the waves that will run fastest.
-    const int take = p.lane_cap;                 // slots per refill: 64, fewer in an underfilled launch
-    int first_pool = -1, first_take = take;
-    bool solo = false;                           // wave-uniform (SOLO kernels): this wave holds only its share of the heaviest pixels
-    bool takes_pixels = (int)(threadIdx.x & 63u) < p.lane_cap;
-    if (SOLO) {
-        // ColdParams::solo_*: wave 0 of the first solo_waves workgroups takes solo_lanes of the top-ranked pixels and
-        // nothing else until they are done; the other waves number their first pools without it.
-        const auto& c = cold_of(p);
-        const int wpb = (int)((blockDim.x + 63) >> 6), w = (int)(threadIdx.x >> 6), b = (int)blockIdx.x;
-        const int ns = c.solo_waves, sl = c.solo_lanes;
-        if (w == 0 && b < ns) {
-            first_pool = b * sl; first_take = sl; solo = true;
-            takes_pixels = (int)(threadIdx.x & 63u) < sl;
-        } else {
-            first_pool = ns * sl + (b * wpb + w - (b < ns ? b + 1 : ns)) * take;
-        }
-    } else if (cold_of(p).first_pools) {
-        first_pool = ((int)blockIdx.x * (int)((blockDim.x + 63) >> 6) + (int)(threadIdx.x >> 6)) * take;
-    }
-    unsigned long long t_start = 0, t_exh = 0;
-    unsigned int it_normal = 0, it_coop = 0, n_pixels = 0;
-    if (COUNT) t_start = __builtin_amdgcn_s_memrealtime();
-    const int lanes_left = (int)blockDim.x - (int)(threadIdx.x & ~63u);
-    const int wave_lanes = lanes_left < 64 ? lanes_left : 64;   // partial last wave of a T x T block
-
-    for (;;) {
-        REGION_BEGIN(total);
-        REGION_BEGIN(refill);
-        if (SOLO && solo && first_pool < 0 && __builtin_amdgcn_ballot_w64(alive) == 0) {   // the solo pixels are done: an ordinary wave from here on
-            solo = false;
-            takes_pixels = (int)(threadIdx.x & 63u) < p.lane_cap;
-        }
-        if (!exhausted && !(SOLO && solo && first_pool < 0) && __builtin_amdgcn_ballot_w64(!alive && takes_pixels) != 0) {
-            bool want = !alive && takes_pixels;
-            PATH_STAT(PS_REFILL);
-            const auto& c = cold_of(p);          // image / shard geometry and buffers: scalar loads here, not live in the path loop
-            const int total_slots = c.total_slots;
-            for (;;) {
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
-                if (m == 0) break;
-                if (pool_next >= pool_end) {     // refill the wave's pool: one atomic per 64 pixels
-                    int base = 0, this_take = take;
-                    if (first_pool >= 0) {       // the first pool follows dispatch order (= wave age), see launch_render
-                        base = first_pool; this_take = first_take;
-                        first_pool = -1;
-                    } else {
-                        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) base = (int)atomicAdd(c.work_counter, (unsigned)take);
-                        base = __builtin_amdgcn_readfirstlane(base);
-                    }
-                    if (base >= total_slots) { exhausted = true; if (COUNT) t_exh = __builtin_amdgcn_s_memrealtime(); break; }
-                    pool_next = base; pool_end = base + this_take;
-                }
-                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                const int avail = pool_end - pool_next;
-                const int wanted = __builtin_popcountll(m);
-                const bool take = want && rank < avail;
-                const int slot = pool_next + rank;
-                pool_next += wanted < avail ? wanted : avail;
-                if (take) {
-                    int jl;
-                    bool valid;
-                    if (c.order) {                               // cost-sorted hand-out (main launch of the sorted schedule)
-                        const int px = c.order[slot];
-                        valid = px >= 0;
-                        jl = valid ? px / c.W : 0;
-                        i = valid ? px - jl * c.W : 0;
-                    } else {                                     // 8x8 tiles, bottom-up
-                        const int tiles_x = (c.W + 7) >> 3, tiles_y = (c.local_rows + 7) >> 3;
-                        const int t = slot >> 6, within = slot & 63;
-                        const int ty = tiles_y - 1 - t / tiles_x, tx = t % tiles_x;
-                        i = tx * 8 + (within & 7);
-                        jl = ty * 8 + (within >> 3);
-                        valid = i < c.W && jl < c.local_rows;    // padded slots of ragged tiles are skipped
-                    }
-                    if (valid) {
-                        want = false;
-                        j = global_row(jl, c.strip_rows, c.nranks, c.rank);
-                        lp = (size_t)jl * c.W + i;
-                        if (c.mid_in) unpark_state<T>(c.mid_in, lp, st);
-                        else {
-                            const size_t npix = (size_t)c.W * c.local_rows;
-                            st.rs.v0 = c.rng_in[0 * npix + lp]; st.rs.v1 = c.rng_in[1 * npix + lp]; st.rs.v2 = c.rng_in[2 * npix + lp];
-                            st.rs.v3 = c.rng_in[3 * npix + lp]; st.rs.v4 = c.rng_in[4 * npix + lp]; st.rs.d = c.rng_in[5 * npix + lp];
-                            st.acc = {0, 0, 0};
-                        }
-                        st.sample = c.s_begin; st.depth = 0;
-                        cost = 0;
-                        if (COUNT) ++n_pixels;
-                        if (c.s_begin < S) { alive = true; fresh = true; }
-                        else { finish_pixel<T>(c, lp, st, cost); want = true; }   // nothing to render in this launch
-                    }
-                }
-            }
-        }
-        REGION_END(refill, RG_REFILL);
-        const unsigned long long alive_mask = __builtin_amdgcn_ballot_w64(alive);
-        if (alive_mask == 0) break;
-        if (alive) PATH_STAT(PS_ITERATION);
-        // one site generates every primary ray: first sample of a new pixel or the next sample
-        REGION_BEGIN(gen);
-#ifdef RTIOW_PROBE_GEN
-        if (alive && fresh) { Rng c = st.rs; rt_opaque(c); V3<T> o2, d2; T u2; gen_primary(p, i, j, c, o2, d2, u2); RT_KEEP1(o2.x); RT_KEEP1(o2.y); RT_KEEP1(o2.z); RT_KEEP1(d2.x); RT_KEEP1(d2.y); RT_KEEP1(d2.z); RT_KEEP1(u2); RT_KEEP1(c.v4); }
-#endif
-        if (alive && fresh) { gen_primary(p, i, j, st.rs, st.O, st.D, st.sky_uy); st.atten = {1, 1, 1}; fresh = false; }
-        REGION_END(gen, RG_GEN_PRIMARY);
-        bool terminated = false;
-        V3<T> col = {0, 0, 0};
-        // hit_world for every lane that still traces (camera.h:84-88), then ONE shade site
-        const bool need_hit = alive && st.depth < p.B;
-        T closest = __builtin_huge_val();
-        int hit = -1;
-        bool share_loops = (exhausted || (SOLO && solo) || 2 * p.lane_cap <= wave_lanes) && 2 * __builtin_popcountll(alive_mask) <= wave_lanes;
-        const unsigned long long hit_mask = __builtin_amdgcn_ballot_w64(need_hit);
-        if (share_loops && p.use_grid && hit_mask != 0) {
-            // With a grid, sharing the brute-force loop only pays while a ray's share of it is short: g lanes per
-            // ray leave it n_trips / g trips of ~38 instructions, the grid path costs ~300 whatever the lane count.
-            const int n_need = __builtin_popcountll(hit_mask);
-            const int lg = lanes_per_ray_log2(n_need, wave_lanes);
-            share_loops = ((p.n_padded >> 2) + (1 << lg) - 1) >> lg <= RTIOW_COOP_MAX_TRIPS;
-        }
-        if (share_loops) {
-            // drain tail: idle lanes share the survivors' sphere loops (hit_world_coop)
-            if (COUNT) ++it_coop;
-            REGION_BEGIN(coop);
-            if (hit_mask != 0) {
-                const T a = dot3(st.D, st.D);
-                if (sizeof(T) == 4 && wave_lanes == 64 && (hit_mask & (hit_mask - 1)) == 0)
-                    coop_solo<SRC>(p, lds_geom, (int)__builtin_ctzll(hit_mask), need_hit, st.O, st.D, a, closest, hit);
-                else
-                    hit_world_coop<T, SRC>(p, lds_geom, coop_slots, need_hit, hit_mask, __builtin_popcountll(hit_mask), wave_lanes, st.O, st.D, a, closest, hit);
-            }
-            REGION_END(coop, RG_HIT_COOP);
-        } else {
-            if (COUNT) ++it_normal;
-            REGION_BEGIN(hw);
-            if (need_hit) {
-                const T a = dot3(st.D, st.D);                 // hittable.h:43, ray-invariant
-#ifdef RTIOW_PROBE_HIT
-                { V3<T> o2 = st.O, d2 = st.D; rt_opaque(o2); rt_opaque(d2); T c2 = __builtin_huge_val(); int h2 = -1; hit_world<T, SRC>(p, lds_geom, o2, d2, dot3(d2, d2), c2, h2); RT_KEEP1(c2); RT_KEEP1(h2); }
-#endif
-                hit_world<T, SRC>(p, lds_geom, st.O, st.D, a, closest, hit);
-            }
-            REGION_END(hw, RG_HIT_WORLD);
-        }
-        REGION_BEGIN(shade);
-#ifdef RTIOW_PROBE_SHADE
-        if (alive && need_hit) { PathState<T> s2 = st; rt_opaque(s2.O); rt_opaque(s2.D); rt_opaque(s2.rs); V3<T> c2; const bool t2 = shade_step<T>(p, lds_shade, s2, closest, hit, c2); RT_KEEP1(c2.x); RT_KEEP1(c2.y); RT_KEEP1(c2.z); RT_KEEP1(s2.O.x); RT_KEEP1(s2.D.x); RT_KEEP1(s2.D.y); RT_KEEP1(s2.D.z); RT_KEEP1(s2.rs.v4); RT_KEEP1(s2.atten.x); RT_KEEP1((int)t2); }
-#endif
-        if (alive) {
-            if (need_hit) { ++cost; if (COUNT) ++nseg; }
-            terminated = need_hit ? shade_step<T>(p, lds_shade, st, closest, hit, col) : true;   // camera.h:127 at the depth limit
-        }
-        REGION_END(shade, RG_SHADE);
-        REGION_BEGIN(acc);
-        if (alive && terminated) {
-            st.acc = {st.acc.x + col.x, st.acc.y + col.y, st.acc.z + col.z};       // camera.h:160
-            ++st.sample;
-            st.depth = 0;
-            if (st.sample < S) fresh = true;
-            else {
-                PATH_STAT(PS_FINISH_PIXEL);
-                const auto& c = cold_of(p);
-                if (COUNT) atomicMax(c.seg_counter + 2, (unsigned long long)cost);   // a pixel's samples are ONE sequential chain: the frame cannot be shorter than the longest
-                finish_pixel<T>(c, lp, st, cost); alive = false;
-            }
-        }
-        REGION_END(acc, RG_ACCUMULATE);
-        REGION_END(total, RG_LOOP_TOTAL);
-    }
-    if (COUNT) {
-        const auto& c = cold_of(p);
-        atomicAdd(c.seg_counter, (unsigned long long)nseg);
-        if (c.timeline) {
-            unsigned int px = n_pixels;
-            for (int off = 32; off > 0; off >>= 1) px += __shfl_xor(px, off, 64);
-            if ((threadIdx.x & 63) == 0) {
-                unsigned long long* o = c.timeline + 8ull * ((unsigned long long)blockIdx.x * ((blockDim.x + 63) >> 6) + (threadIdx.x >> 6));
-                o[0] = t_start; o[1] = t_exh; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = it_normal; o[4] = it_coop; o[5] = px; o[6] = 0; o[7] = 0;
-            }
-        }
-    }
-}
-
-// The same body under two kernel names, so that profiles tell the launches of RTIOW_SCHED_SORTED
-// apart: the prepass (samples [0, SA) in tile order, ~1.4 ms of the headline frame) and the main
-// launch (everything else; also the only launch of RTIOW_SCHED_PERSISTENT).
-template <class T, int SRC, bool COUNT>
-__global__ void __launch_bounds__(1024) render_persistent_kernel(const RenderParams<T> p) { persistent_body<T, SRC, COUNT>(p); }
-template <class T, int SRC, bool COUNT>
-__global__ void __launch_bounds__(1024) render_prepass_kernel(const RenderParams<T> p) { persistent_body<T, SRC, COUNT>(p); }
-// The main launch of a partly filled GPU (small frame, shard of a multi-GPU frame): the same body with the solo
-// waves of ColdParams::solo_* compiled in (a kernel of its own, so that the full-frame launch does not carry the
-// wave-uniform bookkeeping: +1 % measured).
-template <class T, int SRC>
-__global__ void __launch_bounds__(1024) render_solo_kernel(const RenderParams<T> p) { persistent_body<T, SRC, false, true>(p); }
-
-// Elementwise arithmetic probes (tests compare these with the host bit for bit).
-template <class T>
-__global__ void debug_ops_kernel(int op, size_t n, const T* a, const T* b, const T* c, T* out) {
-    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    switch (op) {
-        case 0: out[k] = a[k] / b[k]; break;
-        case 1: out[k] = Real<T>::sqrt(a[k]); break;
-        case 2: out[k] = Real<T>::fma(a[k], b[k], c[k]); break;
-        case 3: { uint32_t x; memcpy(&x, &a[k], 4); out[k] = Real<T>::from_u32(x); break; }
-        case 4: out[k] = a[k] * b[k] + c[k]; break;
-        default: out[k] = 0;
-    }
-}
-
-// hit_world alone on caller-supplied rays, one per lane (rtiow_debug_hit_world): the tests feed it rays a
-// render never produces and compare the scene sources ray by ray.
-template <class T>
-__global__ void __launch_bounds__(256) hit_probe_kernel(const RenderParams<T> p, const T* __restrict__ rays, int n, T* __restrict__ out_t, int* __restrict__ out_idx) {
-    const T* lds_geom = stage_scene<T, RTIOW_SCENE_LDS>(p);
-    for (int base = (int)blockIdx.x * (int)blockDim.x; base < n; base += (int)gridDim.x * (int)blockDim.x) {
-        const int k = base + (int)threadIdx.x;
-        if (k < n) {
-            const V3<T> O = {rays[6 * (size_t)k], rays[6 * (size_t)k + 1], rays[6 * (size_t)k + 2]};
-            const V3<T> D = {rays[6 * (size_t)k + 3], rays[6 * (size_t)k + 4], rays[6 * (size_t)k + 5]};
-            T closest = __builtin_huge_val();
-            int hit = -1;
-            hit_world<T, RTIOW_SCENE_LDS>(p, lds_geom, O, D, dot3(D, D), closest, hit);
-            out_t[k] = closest; out_idx[k] = hit;
-        }
-    }
-}
-
-// ---- SCHED_SORTED: counting sort of the pixels by the cost measured in the prepass, heavy first,
-// dealt into balanced pools.  Sorted rank r -> slot: ranks are cut into blocks of
-// `pools_per_block` pools (the resident waves of one dispatch-age class); inside a block groups of
-// `group` consecutive ranks go to consecutive pools, so every pool of a block gets the same mix of
-// costs and the blocks run from the heaviest pixels to the lightest.  Ranks inside a cost bin follow
-// the image (64 x 64 super-tiles, 8 x 8 tiles), so a group is a handful of neighbouring pixels.
-constexpr int COST_BINS = 1024;
-__device__ __forceinline__ int cost_bin(unsigned c) { return c < (unsigned)COST_BINS ? (int)c : COST_BINS - 1; }
-
-// What the sort ranks a pixel by: the prepass cost averaged over its (2 hw + 1)^2 neighbourhood (inside its
-// own row strip), in quarter segments.  A pixel's own 3 samples predict the cost of its remaining 97 poorly
-// (correlation 0.51 on the oracle's segment maps: half a percent of the heaviest pixels were handed out after
-// more than half of the frame's work); heavy pixels cluster -- the rims of the glass spheres, the crevices
-// between spheres -- and the 75 samples of a 5 x 5 neighbourhood predict it well (0.91; the same pixels then
-// start within the first 16 %).  Measured: headline 14.6 -> 13.5 ms, 1280x720 10.0 -> 8.6, half-frame shard
-// 10.6 -> 8.5, scene 1 26.0 -> 23.8 (hw = 6).  hw = half-width of the window.  `strip_rows` = the rows that are
-// neighbours in the image: a rank's strip in a sharded frame (windows that cross into the rank's next strip, N x
-// strip rows away, rank the pixels worse: 1/4 frame 6.4 -> 7.2 ms), the whole frame on one rank (until the end of
-// round 2 the window stopped at the default 8-row strips there too: 1280x720 8.3 -> 7.9 ms, headline 13.4 -> 13.3,
-// profiles/r02_handout_study/sweep8_smoothing_window.txt; half-widths 5-10 are equal, sweep9).
-// One workgroup smooths a 64 x 16 tile from LDS: the tile with its halo, then the horizontal window sums of every
-// row it needs, then the vertical sums (26 LDS reads per pixel instead of 169 cached global loads: 61 -> 20 us on
-// the full frame).  Integer sums: the same values in any order.
-// The histogram of the keys (what cost_hist_kernel counts for an unsmoothed key) rides along: one LDS histogram
-// per tile, one global atomic per non-empty bin.
-constexpr int SMOOTH_TW = 64, SMOOTH_TH = 16;
-__global__ void __launch_bounds__(256) cost_smooth_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ out, int W, int rows, int strip_rows, int hw,
-                                                          unsigned* __restrict__ hist) {
-    extern __shared__ uint32_t smooth_lds[];
-    __shared__ unsigned tile_hist[COST_BINS];
-    for (int b = threadIdx.x; b < COST_BINS; b += blockDim.x) tile_hist[b] = 0;
-    const int halo_w = SMOOTH_TW + 2 * hw, halo_h = SMOOTH_TH + 2 * hw;
-    uint32_t* tile = smooth_lds;                       // [halo_h][halo_w], zero outside the image
-    uint32_t* hsum = smooth_lds + halo_w * halo_h;     // [halo_h][SMOOTH_TW]
-    const int tiles_x = (W + SMOOTH_TW - 1) / SMOOTH_TW;
-    const int tx = (int)blockIdx.x % tiles_x, ty = (int)blockIdx.x / tiles_x;
-    const int x_base = tx * SMOOTH_TW - hw, y_base = ty * SMOOTH_TH - hw;
-    for (int k = threadIdx.x; k < halo_w * halo_h; k += blockDim.x) {
-        const int ly = k / halo_w, lx = k - ly * halo_w;
-        const int x = x_base + lx, y = y_base + ly;
-        tile[k] = (x >= 0 && x < W && y >= 0 && y < rows) ? cost[y * W + x] : 0u;
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < SMOOTH_TW * halo_h; k += blockDim.x) {
-        const int ly = k / SMOOTH_TW, lx = k - ly * SMOOTH_TW;
-        unsigned sum = 0;
-        for (int d = 0; d <= 2 * hw; ++d) sum += tile[ly * halo_w + lx + d];     // columns outside the image hold 0
-        hsum[k] = sum;
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < SMOOTH_TW * SMOOTH_TH; k += blockDim.x) {
-        const int ly = k / SMOOTH_TW, lx = k - ly * SMOOTH_TW;
-        const int i = tx * SMOOTH_TW + lx, jl = ty * SMOOTH_TH + ly;
-        if (i >= W || jl >= rows) continue;
-        const int s0 = (jl / strip_rows) * strip_rows;                               // rows of other strips are not neighbours in the image
-        const int j0 = jl - hw > s0 ? jl - hw : s0;
-        int j1 = jl + hw < s0 + strip_rows - 1 ? jl + hw : s0 + strip_rows - 1;
-        if (j1 > rows - 1) j1 = rows - 1;
-        const int i0 = i - hw > 0 ? i - hw : 0, i1 = i + hw < W - 1 ? i + hw : W - 1;
-        unsigned sum = 0;
-        for (int j = j0; j <= j1; ++j) sum += hsum[(j - y_base) * SMOOTH_TW + lx];
-        // mean over the window actually covered, in quarter segments: the bins keep their resolution at the image
-        // border and in two-row strips
-        const unsigned cells = (unsigned)((j1 - j0 + 1) * (i1 - i0 + 1));
-        const unsigned key = (4u * sum + cells / 2) / cells;
-        out[jl * W + i] = key;
-        atomicAdd(&tile_hist[cost_bin(key)], 1u);
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < COST_BINS; b += blockDim.x) if (tile_hist[b]) atomicAdd(&hist[b], tile_hist[b]);
-}
-
-__global__ void __launch_bounds__(256) cost_hist_kernel(const uint32_t* __restrict__ cost, int npix, unsigned* __restrict__ hist) {
-    __shared__ unsigned local[COST_BINS];
-    for (int b = threadIdx.x; b < COST_BINS; b += blockDim.x) local[b] = 0;
-    __syncthreads();
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < npix; k += gridDim.x * blockDim.x) {
-        atomicAdd(&local[cost_bin(cost[k])], 1u);
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < COST_BINS; b += blockDim.x) if (local[b]) atomicAdd(&hist[b], local[b]);
-}
-
-// start[b] = number of pixels with a HIGHER bin (heavy first); also zeroes the fill counters.
-__global__ void __launch_bounds__(COST_BINS) cost_scan_kernel(const unsigned* __restrict__ hist, unsigned* __restrict__ start, unsigned* __restrict__ fill) {
-    __shared__ unsigned tmp[COST_BINS];
-    const int b = threadIdx.x;
-    tmp[b] = hist[COST_BINS - 1 - b];            // reversed: index 0 = heaviest bin
-    __syncthreads();
-    for (int off = 1; off < COST_BINS; off <<= 1) {
-        const unsigned v = b >= off ? tmp[b - off] : 0;
-        __syncthreads();
-        tmp[b] += v;
-        __syncthreads();
-    }
-    start[COST_BINS - 1 - b] = tmp[b] - hist[COST_BINS - 1 - b];   // exclusive
-    fill[b] = 0;
-}
-
-// Each 1024-thread block ranks 4096 pixels: a block-private histogram in LDS, ONE global atomic per
-// non-empty bin to reserve the block's range of ranks, then LDS atomics for the rank inside it
-// (2 M contended global atomics on ~20 hot bins took 17.8 ms; this takes microseconds).
-constexpr int SCATTER_PER_THREAD = 4;
-__global__ void __launch_bounds__(1024) cost_scatter_kernel(const uint32_t* __restrict__ cost, int W, int rows, const unsigned* __restrict__ start,
-                                                            unsigned* __restrict__ fill, int* __restrict__ order, int pools_per_block, int total_pools, int group,
-                                                            int solo_slots) {
-    __shared__ unsigned local[COST_BINS];        // block histogram, then the running rank inside the reserved range
-    __shared__ unsigned base[COST_BINS];
-    for (int b = threadIdx.x; b < COST_BINS; b += blockDim.x) local[b] = 0;
-    __syncthreads();
-    // A block ranks one 64 x 64-pixel super-tile, each wave an 8 x 8 tile of it, so that pixels which
-    // are neighbours in the image and equal in cost get adjacent ranks (see `group` below).
-    const int st_x = (W + 63) >> 6;
-    const int sx = (int)blockIdx.x % st_x, sy = (int)blockIdx.x / st_x;
-    int bins[SCATTER_PER_THREAD], pix[SCATTER_PER_THREAD];
-#pragma unroll
-    for (int u = 0; u < SCATTER_PER_THREAD; ++u) {
-        const int idx = u * (int)blockDim.x + (int)threadIdx.x, tile = idx >> 6, within = idx & 63;
-        const int px = sx * 64 + (tile & 7) * 8 + (within & 7), py = sy * 64 + (tile >> 3) * 8 + (within >> 3);
-        const int k = (px < W && py < rows) ? py * W + px : -1;
-        pix[u] = k;
-        bins[u] = -1;
-        if (k >= 0) {
-            bins[u] = cost_bin(cost[k]);
-            atomicAdd(&local[bins[u]], 1u);
-        }
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < COST_BINS; b += blockDim.x) {
-        const unsigned n = local[b];
-        base[b] = n ? start[b] + atomicAdd(&fill[b], n) : 0;
-        local[b] = 0;
-    }
-    __syncthreads();
-    const int per_block = pools_per_block * POOL;
-#pragma unroll
-    for (int u = 0; u < SCATTER_PER_THREAD; ++u) {
-        if (bins[u] < 0) continue;
-        const int k = pix[u];
-        int r = (int)(base[bins[u]] + atomicAdd(&local[bins[u]], 1u));   // sorted rank (order inside a bin is immaterial)
-        if (r < solo_slots) { order[r] = k; continue; }              // the heaviest pixels: slot = rank, handed to the solo waves
-        r -= solo_slots;
-        const int blk = r / per_block, q = r - blk * per_block;
-        const int pools_here = (blk + 1) * pools_per_block <= total_pools ? pools_per_block : total_pools - blk * pools_per_block;
-        const int g = q / group, j = q - g * group;                 // groups of `group` consecutive ranks stay together
-        const int pool = blk * pools_per_block + g % pools_here;
-        const int lane_slot = (g / pools_here) * group + j;
-        order[solo_slots + pool * POOL + lane_slot] = k;
-    }
-}
-
-// =====================================================================================
-// host side of the library
-// =====================================================================================
-struct Mat160 { uint32_t col[XW_BITS][XW_WORDS]; };
-
-void mat_vec(const Mat160& m, const uint32_t* in, uint32_t* out) {
-    uint32_t acc[XW_WORDS] = {0, 0, 0, 0, 0};
-    for (int w = 0; w < XW_WORDS; ++w)
-        for (uint32_t bits = in[w]; bits; bits &= bits - 1) {          // the set bits only
-            const uint32_t* c = m.col[w * 32 + __builtin_ctz(bits)];
-            for (int k = 0; k < XW_WORDS; ++k) acc[k] ^= c[k];
-        }
-    std::memcpy(out, acc, sizeof acc);
-}
-
-// Jump matrices A^(2^(67+b)), b = 0..31, of the xorshift part of XORWOW (A = the one-step matrix,
-// built by pushing the 160 basis vectors through the generator).  A^(2^67) is a committed constant
-// (xorwow_jump67.inc, written by gen/gen_xorwow_jump67.cpp), so a process pays 31 squarings instead
-// of 98; `from_scratch` derives everything from A and is what the tests compare the constant with.
-// `count` = how many of the 32 to build: rng_init_kernel reads matrix b only when bit b of a pixel index is set.
-const uint32_t kJump67[XW_BITS * XW_WORDS] = {
-#include "xorwow_jump67.inc"
-};
-
-std::vector<uint32_t> build_sequence_jump_matrices(bool from_scratch = false, int count = XW_JUMPS) {
-    Mat160 cur, nxt;
-    int done = 0;
-    if (from_scratch) {
-        for (int b = 0; b < XW_BITS; ++b) {
-            uint32_t v[XW_WORDS] = {0, 0, 0, 0, 0};
-            v[b >> 5] = 1u << (b & 31);
-            const uint32_t t = v[0] ^ (v[0] >> 2);
-            const uint32_t n4 = (v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1));
-            cur.col[b][0] = v[1]; cur.col[b][1] = v[2]; cur.col[b][2] = v[3]; cur.col[b][3] = v[4]; cur.col[b][4] = n4;
-        }
-    } else {
-        std::memcpy(&cur.col[0][0], kJump67, sizeof kJump67);
-        done = 67;
-    }
-    std::vector<uint32_t> out;
-    out.reserve((size_t)count * XW_MAT_WORDS);
-    for (int e = done; e < 67 + count; ++e) {
-        if (e >= 67) out.insert(out.end(), &cur.col[0][0], &cur.col[0][0] + XW_MAT_WORDS);
-        if (e + 1 == 67 + count) break;
-        for (int b = 0; b < XW_BITS; ++b) mat_vec(cur, cur.col[b], nxt.col[b]);
-        cur = nxt;
-    }
-    return out;
-}
-
-}  // namespace
-
-struct rtiow_handle_s {
-    int device = 0;
-    int precision = 32;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_a = nullptr, ev_b = nullptr;   // ev_a: prepass done, ev_b: main launch starts
-    bool time_phases = false;
-    bool render_pending = false;                  // rtiow_render_async recorded its stop event, rtiow_render_wait has not read it yet
-    std::string err;
-
-    // scene
-    int n = 0, n_padded = 0;
-    void *geom_a = nullptr, *shade_tbl = nullptr;
-    void* geom_s = nullptr;                       // screening table (built lazily at the first render of a scene)
-    std::vector<double> host_cr;                  // compact {cx,cy,cz,r} kept for building it
-    bool screen_dirty = true;
-    double ctr[3] = {0, 0, 0}, omax2 = 0;
-    // uniform grid over the small spheres (RTIOW_SCENE_GRID; built with the screening table)
-    void* grid_blob = nullptr;
-    GridParams grid{};                            // offsets are relative to the blob until launch_render places it in LDS
-    int grid_cells_bytes = 0, grid_aos_bytes = 0, grid_direct_bytes = 0, grid_ids_bytes = 0;
-    int grid_direct = 0, grid_registered = 0;
-    // camera
-    bool have_camera = false;
-    rtiow_camera_f32 cam32{};
-    rtiow_camera_f64 cam64{};
-    // shard
-    int rank = 0, nranks = 1, strip_rows = 8;
-    int local_rows = 0;
-    // rng
-    uint32_t* rng = nullptr;
-    size_t rng_pixels = 0;
-    bool rng_ready = false;
-    uint32_t* jump = nullptr;
-    int jump_count = 0;                           // matrices of `jump` that are filled: enough for the bits of the largest pixel index so far
-    // framebuffer
-    void* fb = nullptr;
-    size_t fb_bytes = 0;
-    bool fb_external = false;
-    // knobs / stats
-    int scene_source = RTIOW_SCENE_GRID;
-    int schedule = RTIOW_SCHED_SORTED;
-    unsigned char* mid = nullptr; size_t mid_bytes = 0;          // SCHED_SORTED: MidState records parked between the launches
-    uint32_t* cost = nullptr; size_t cost_bytes = 0;
-    uint32_t* cost_rank = nullptr; size_t cost_rank_bytes = 0;    // the smoothed cost the sort ranks by
-    int* order = nullptr; size_t order_bytes = 0;
-    unsigned* sort_scratch = nullptr; size_t sort_scratch_bytes = 0;
-    int waves_per_simd = 0;
-    int num_cus = 256;
-    int last_count_blocks = 0, last_count_waves_per_block = 0;
-    size_t timeline_cap_waves = 0;            // waves the debug timeline buffer holds
-    unsigned int* work_counter = nullptr;
-    unsigned long long* timeline = nullptr;   // debug: set only during rtiow_debug_timeline
-    int probe_n = 0; const void* probe_rays = nullptr; void* probe_t = nullptr; int* probe_idx = nullptr;   // debug: set only during rtiow_debug_hit_world
-    rtiow_stats stats{};
-};
-
-namespace {
-
-size_t elem_size(const rtiow_handle_s* h) { return h->precision == 64 ? 8 : 4; }
-
-int fail(rtiow_handle_s* h, hipError_t e, const char* file, int line) {
-    char buf[512];
-    // same text the reference's CUDA_SAFE_CALL prints (main.cu:16-17)
-    std::snprintf(buf, sizeof buf, "HIP_SAFE_CALL: %s %s %d", hipGetErrorString(e), file, line);
-    if (h) h->err = buf;
-    return (int)e;
-}
-int fail_arg(rtiow_handle_s* h, int code, const char* msg) { if (h) h->err = msg; return code; }
-
-#define HIP_TRY(h, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail((h), e_, __FILE__, __LINE__); } while (0)
-
-// Device memory of one call: released on every return path (HIP_TRY returns early).
-struct DeviceScratch {
-    void* ptr = nullptr;
-    hipError_t alloc(size_t bytes) { return hipMalloc(&ptr, bytes); }
-    ~DeviceScratch() { if (ptr) (void)hipFree(ptr); }
-    DeviceScratch() = default;
-    DeviceScratch(const DeviceScratch&) = delete;
-    DeviceScratch& operator=(const DeviceScratch&) = delete;
-};
-
-int compute_local_rows(int H, int rank, int nranks, int strip_rows) {
-    int rows = 0;
-    const int nstrips = (H + strip_rows - 1) / strip_rows;
-    for (int s = rank; s < nstrips; s += nranks) {
-        const int r0 = s * strip_rows;
-        rows += (r0 + strip_rows <= H) ? strip_rows : (H - r0);
-    }
-    return rows;
-}
-
-int img_w(const rtiow_handle_s* h) { return h->precision == 64 ? h->cam64.img_width : h->cam32.img_width; }
-int img_h(const rtiow_handle_s* h) { return h->precision == 64 ? h->cam64.img_height : h->cam32.img_height; }
-
-int ensure_framebuffer(rtiow_handle_s* h) {
-    const size_t need = (size_t)h->local_rows * img_w(h) * 3 * elem_size(h);
-    if (h->fb_external) {
-        if (h->fb_bytes < need) return fail_arg(h, RTIOW_E_BADARG, "bound framebuffer too small");
-        return 0;
-    }
-    if (h->fb && h->fb_bytes >= need) return 0;
-    if (h->fb) { HIP_TRY(h, hipFree(h->fb)); h->fb = nullptr; h->fb_bytes = 0; }
-    if (need == 0) return 0;
-    HIP_TRY(h, hipMalloc(&h->fb, need));
-    h->fb_bytes = need;
-    return 0;
-}
-
-// Can gen_primary take 1/sqrt(|D|^2) without range handling (inv_sqrt_accepted)?  D = pixel sample - lens point:
-// the samples lie in the pixel plane (pixel00 + fi du + fj dv, fi in [-0.5, W - 0.5]), the lens points on the
-// defocus disk around the centre (|px|, |py| <= 1).  |D| is at most the sum of the extents and at least the
-// distance of the lens from the pixel plane; both with room for the fp32 rounding of coordinates up to M.
-template <class CAM>
-int primary_rays_in_range(const CAM& c) {
-    auto v = [](const auto* a) { return std::array<double, 3>{(double)a[0], (double)a[1], (double)a[2]}; };
-    auto dot = [](const std::array<double, 3>& a, const std::array<double, 3>& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
-    auto len = [&](const std::array<double, 3>& a) { return std::sqrt(dot(a, a)); };
-    const auto ctr = v(c.center), p00 = v(c.pixel00_loc), du = v(c.pixel_delta_u), dv = v(c.pixel_delta_v);
-    std::array<double, 3> ddu = v(c.defocus_disk_u), ddv = v(c.defocus_disk_v);
-    if (c.defocus_angle <= 0) ddu = ddv = {0, 0, 0};
-    const std::array<double, 3> rel = {p00[0] - ctr[0], p00[1] - ctr[1], p00[2] - ctr[2]};
-    std::array<double, 3> n = {du[1] * dv[2] - du[2] * dv[1], du[2] * dv[0] - du[0] * dv[2], du[0] * dv[1] - du[1] * dv[0]};
-    const double nl = len(n);
-    if (!(nl > 0) || !std::isfinite(nl)) return 0;
-    n = {n[0] / nl, n[1] / nl, n[2] / nl};
-    const double W = c.img_width + 1.0, H = c.img_height + 1.0;
-    const double dmax = len(rel) + W * len(du) + H * len(dv) + len(ddu) + len(ddv);
-    const double dmin = std::fabs(dot(rel, n)) - std::fabs(dot(ddu, n)) - std::fabs(dot(ddv, n));
-    const double M = len(ctr) + len(p00) + W * len(du) + H * len(dv) + len(ddu) + len(ddv);   // largest coordinate in play
-    const double slack = M * 0x1p-18;                                                          // >> the fp32 rounding of ps, org and D
-    return std::isfinite(dmax) && dmax + slack < 0x1p30 && dmin - slack > 0x1p-30;
-}
-
-// FastDiv (above ieee_roots): every sphere (centre +- radius) and the lens within 2^18 of the origin.
-template <class CAM>
-int scene_in_range(const rtiow_handle_s* h, const CAM& c) {
-    double reach = 0;
-    for (size_t i = 0; i + 3 < h->host_cr.size(); i += 4)
-        for (int k = 0; k < 3; ++k) reach = std::fmax(reach, std::fabs(h->host_cr[i + k]) + std::fabs(h->host_cr[i + 3]));
-    for (int k = 0; k < 3; ++k)
-        reach = std::fmax(reach, std::fabs((double)c.center[k]) + std::fabs((double)c.defocus_disk_u[k]) + std::fabs((double)c.defocus_disk_v[k]));
-    return !h->host_cr.empty() && std::isfinite(reach) && reach < 0x1p18;
-}
-
-template <class T, class CAM>
-RenderParams<T> make_params(const rtiow_handle_s* h, const CAM& c) {
-    RenderParams<T> p;
-    p.range_flags = primary_rays_in_range(c) | (scene_in_range(h, c) << 1);
-    p.cold.W = c.img_width; p.cold.H = c.img_height; p.cold.S = c.samples_per_pixel; p.B = c.max_depth;
-    p.cold.pixel_samples_scale = c.pixel_samples_scale;
-    p.center = {c.center[0], c.center[1], c.center[2]};
-    p.pixel00 = {c.pixel00_loc[0], c.pixel00_loc[1], c.pixel00_loc[2]};
-    p.du = {c.pixel_delta_u[0], c.pixel_delta_u[1], c.pixel_delta_u[2]};
-    p.dv = {c.pixel_delta_v[0], c.pixel_delta_v[1], c.pixel_delta_v[2]};
-    p.defocus_angle = c.defocus_angle;
-    p.ddu = {c.defocus_disk_u[0], c.defocus_disk_u[1], c.defocus_disk_u[2]};
-    p.ddv = {c.defocus_disk_v[0], c.defocus_disk_v[1], c.defocus_disk_v[2]};
-    p.n = h->n; p.n_padded = h->n_padded;
-    p.geom_a = (const T*)h->geom_a; p.shade_tbl = (const T*)h->shade_tbl;
-    p.cold.rng = h->rng; p.cold.fb = (T*)h->fb;
-    p.cold.local_rows = h->local_rows; p.cold.rank = h->rank; p.cold.nranks = h->nranks; p.cold.strip_rows = h->strip_rows;
-    return p;
-}
-
-template <class T>
-int upload_scene(rtiow_handle_s* h, int n, const T* cr, const T* af, const T* ri, const int32_t* type, const int32_t* valid) {
-    std::vector<T> ga, st;
-    int m = 0;
-    for (int i = 0; i < n; ++i) {
-        if (valid && !valid[i]) continue;
-        const T cx = cr[4 * i], cy = cr[4 * i + 1], cz = cr[4 * i + 2], r = cr[4 * i + 3];
-        if (type[i] < 0 || type[i] > 2) return fail_arg(h, RTIOW_E_BADARG, "material type out of range");
-        ga.insert(ga.end(), {cx, cy, cz, (T)(r * r)});          // hittable.h:45 radius*radius
-        // words 4..7: albedo and fuzz; a dielectric uses neither (material.h:70), its record carries Schlick's
-        // r0^2 = ((1 - ri) / (1 + ri))^2 for ri = 1/eta (front face) and ri = eta (back face) instead, computed here
-        // with the operations of material.h:62-66 in T (no contraction on the host either)
-        auto r0sq = [](T ri_) { T r0 = ((T)1 - ri_) / ((T)1 + ri_); return (T)(r0 * r0); };
-        const bool glass = type[i] == RTIOW_DIELECTRIC;
-        st.insert(st.end(), {cx, cy, cz, (T)((T)1 / r),         // vec3.h:89-91 (1/t)*v
-                             glass ? r0sq((T)((T)1 / ri[i])) : af[4 * i], glass ? r0sq(ri[i]) : af[4 * i + 1], af[4 * i + 2], af[4 * i + 3],
-                             ri[i], (T)((T)1 / ri[i]),          // material.h:73 1.0f/refraction_index
-                             (T)type[i], (T)0});
-        ++m;
-    }
-    if (m == 0) return fail_arg(h, RTIOW_E_BADARG, "scene has no valid spheres");
-    const int mp = (m + 4) / 4 * 4;                         // >= one padding entry: index m is the never-hit sphere that grid cells pad with
-    for (int i = m; i < mp; ++i) ga.insert(ga.end(), {(T)0, (T)0, (T)0, (T)-1e12});   // c = |oc|^2 + 1e12 => disc < 0: never hit
-    if (sizeof(T) == 4) {                                    // fp32: pair-interleave for v_pk_*_f32 (trip_discriminants)
-        std::vector<T> pi(ga.size());
-        for (int q = 0; q < mp / 2; ++q)
-            for (int k = 0; k < 4; ++k) { pi[8 * q + 2 * k] = ga[8 * q + k]; pi[8 * q + 2 * k + 1] = ga[8 * q + 4 + k]; }
-        ga.swap(pi);
-    }
-    h->host_cr.clear();
-    for (int i = 0; i < n; ++i)
-        if (!valid || valid[i]) for (int k = 0; k < 4; ++k) h->host_cr.push_back((double)cr[4 * i + k]);
-    h->screen_dirty = true;
-    void** bufs[] = {&h->geom_a, &h->shade_tbl};
-    for (void** b : bufs) if (*b) { HIP_TRY(h, hipFree(*b)); *b = nullptr; }
-    HIP_TRY(h, hipMalloc(&h->geom_a, sizeof(T) * 4 * mp));
-    HIP_TRY(h, hipMalloc(&h->shade_tbl, sizeof(T) * 12 * m));
-    HIP_TRY(h, hipMemcpy(h->geom_a, ga.data(), sizeof(T) * 4 * mp, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->shade_tbl, st.data(), sizeof(T) * 12 * m, hipMemcpyHostToDevice));
-    h->n = m; h->n_padded = mp;
-    h->stats.num_spheres = m;
-    return 0;
-}
-
-// Builds the screening table of hit_world_screened for the current scene: centres recentred on
-// the scene's centroid (ground-like spheres excluded), q' = |C'|^2 - r^2 - 2^-17 (|C'|^2 + r^2)
-// rounded DOWN; always fp32 and pair-interleaved like the fp32 geom_a (the fp64 kernel screens in
-// fp32 too).  2 Cmax goes to the kernel for the per-ray share of the margin.
-template <class T>
-int build_screen_table(rtiow_handle_s* h) {
-    typedef float S;                                        // the screen runs in fp32 for both precisions
-    const int m = h->n, mp = h->n_padded;
-    const std::vector<double>& cr = h->host_cr;
-    double ctr[3] = {0, 0, 0};
-    int cnt = 0;
-    for (int i = 0; i < m; ++i)
-        if (cr[4 * i + 3] < 100.0) { for (int k = 0; k < 3; ++k) ctr[k] += cr[4 * i + k]; ++cnt; }
-    if (cnt) for (int k = 0; k < 3; ++k) ctr[k] /= cnt;
-    for (int k = 0; k < 3; ++k) h->ctr[k] = (double)(T)ctr[k];
-    std::vector<S> lin((size_t)mp * 4);
-    double cmax = 0;                                        // max |C'| over the spheres that are screened
-    for (int i = 0; i < mp; ++i) {
-        if (i >= m) { lin[4 * i] = lin[4 * i + 1] = lin[4 * i + 2] = 0; lin[4 * i + 3] = (S)1e12; continue; }   // padding: c~ huge => never a candidate
-        double c2 = 0;
-        for (int k = 0; k < 3; ++k) {
-            const S cp = (S)(cr[4 * i + k] - h->ctr[k]);    // what the kernel will use as C'
-            lin[4 * i + k] = cp;
-            c2 += (double)cp * (double)cp;
-        }
-        if (std::sqrt(c2) > 64.0) { lin[4 * i + 3] = (S)-1e30; continue; }         // e.g. the ground: always re-tested exactly
-        cmax = std::max(cmax, std::sqrt(c2));
-        const double r = cr[4 * i + 3], r2 = r * r;
-        const double kappa = std::ldexp(1.0, -17) * (c2 + r2);                     // the sphere's share of the margin
-        S q = (S)(c2 - r2 - kappa);
-        if ((double)q > c2 - r2 - kappa) q = std::nextafter(q, (S)-INFINITY);
-        lin[4 * i + 3] = q;
-    }
-    h->omax2 = 2.0 * cmax * 1.000001;                       // per-ray share uses 2 Cmax |O'| + |O'|^2; the slack covers the raw sqrt (<= 2^-22 relative) in the kernel
-    {
-        std::vector<S> pi(lin.size());
-        for (int q = 0; q < mp / 2; ++q)
-            for (int k = 0; k < 4; ++k) { pi[8 * q + 2 * k] = lin[8 * q + k]; pi[8 * q + 2 * k + 1] = lin[8 * q + 4 + k]; }
-        lin.swap(pi);
-    }
-    if (h->geom_s) { HIP_TRY(h, hipFree(h->geom_s)); h->geom_s = nullptr; }
-    HIP_TRY(h, hipMalloc(&h->geom_s, lin.size() * sizeof(S)));
-    HIP_TRY(h, hipMemcpy(h->geom_s, lin.data(), lin.size() * sizeof(S), hipMemcpyHostToDevice));
-    h->screen_dirty = false;
-    return 0;
-}
-
-// The plan of the uniform grid of hit_world_grid for a scene: pure host arithmetic (no GPU), shared by
-// build_grid_tables and the rtiow_debug_grid_plan test hook.
-//
-//  small sphere    : registration half-width w_i = sqrt(r_i^2 + E_i) + eps <= cell / 2, where
-//                    E_i = 18 * 2^-24 ((Rfar + Cmax)^2 + r_i^2) bounds the reference's discriminant
-//                    noise for every origin within Rfar of the recentring point (hit_world_grid);
-//  cell            : about one small sphere per cell, never narrower than the widest small sphere;
-//  registration    : sphere i goes into every cell its square [c - w, c + w]^2 touches (<= 2 x 2),
-//                    in index order; a sphere that meets a full cell (4 entries) joins the direct list;
-//  direct list     : everything else (ground, big spheres, overflow), tested exactly by every ray.
-// Candidate "small" sets: every finite sphere, then without the largest radii, and so on; each
-// candidate whose cells are at least as wide as its widest member is registered, and the plan with the
-// shortest direct list wins.  `usable` stays false when the grid would not pay (few small spheres,
-// or a direct list that is no shorter than a fraction of the scene): the scene keeps the screened loop.
-struct GridPlan {
-    bool usable = false;
-    int nx = 0, nz = 0, registered = 0;
-    float cellf = 0, x0f = 0, z0f = 0;
-    double rfar = 0, eps = 0, ylo = 1e300, yhi = -1e300, core_lo[3] = {1e300, 1e300, 1e300}, core_hi[3] = {-1e300, -1e300, -1e300}, rmax_g = 0, cmax_g = 0;
-    std::vector<uint16_t> cells;        // [nz][nx][4]: sphere indices, 0xffff x4 = empty cell, index m = never-hit pad
-    std::vector<int> direct;
-    std::vector<double> halfwidth;      // w_i of the registered spheres (0 for the direct list)
-};
-
-GridPlan plan_grid(int m, const std::vector<double>& cr, const double* ctr) {
-    GridPlan best;
-    if (m < 24 || m > 60000) return best;
-    std::vector<double> radii(m);
-    for (int i = 0; i < m; ++i) radii[i] = cr[4 * i + 3];
-    std::vector<int> small;
-    for (int i = 0; i < m; ++i) {
-        bool ok = radii[i] > 0 && std::isfinite(radii[i]);
-        for (int k = 0; k < 3; ++k) ok = ok && std::isfinite(cr[4 * i + k]);
-        if (ok) small.push_back(i);
-    }
-    std::sort(small.begin(), small.end(), [&](int a, int b) { return radii[a] < radii[b] || (radii[a] == radii[b] && a < b); });
-    const double u18 = 18.0 * std::ldexp(1.0, -24) * 1.01;
-    bool have = false;
-    std::vector<double> w(m, 0.0);
-    for (int attempt = 0; attempt < 12 && (int)small.size() >= 16; ++attempt) {
-        double cmax = 0, lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, rmax = 0;
-        for (int i : small) {
-            double d2 = 0;
-            for (int k = 0; k < 3; ++k) { const double d = cr[4 * i + k] - ctr[k]; d2 += d * d; lo[k] = std::min(lo[k], cr[4 * i + k]); hi[k] = std::max(hi[k], cr[4 * i + k]); }
-            cmax = std::max(cmax, std::sqrt(d2));
-            rmax = std::max(rmax, radii[i]);
-        }
-        const double cut = 0.9 * rmax;                                  // the next candidate drops the largest radii
-        cmax *= 1.0001;
-        const double rfar = std::max(64.0, 4.0 * cmax);
-        double cabs = 0;
-        for (int k = 0; k < 3; ++k) cabs = std::max(cabs, std::fabs(ctr[k]));
-        const double L = 2.0 * (rfar + cmax) + cabs + rmax;            // every coordinate the walk handles is smaller
-        const double eps = std::ldexp(L, -16);
-        double wmax = 0;
-        for (int i : small) {
-            const double E = u18 * ((rfar + cmax) * (rfar + cmax) + radii[i] * radii[i]);
-            w[i] = std::sqrt(radii[i] * radii[i] + E) + eps;
-            wmax = std::max(wmax, w[i]);
-        }
-        const double ext_x = (hi[0] - lo[0]) + 2 * wmax, ext_z = (hi[2] - lo[2]) + 2 * wmax;
-        double cell = std::sqrt(ext_x * ext_z / (double)small.size());
-        if (L < 1e6 && cell >= 2.0 * (wmax + eps) * 1.02) {
-            GridPlan pl;
-            for (;;) {
-                pl.nx = (int)std::ceil(ext_x / cell) + 1; pl.nz = (int)std::ceil(ext_z / cell) + 1;
-                if ((long long)pl.nx * pl.nz <= 4096) break;
-                cell *= 1.25;
-            }
-            pl.cellf = (float)cell; pl.rfar = rfar; pl.eps = eps;
-            pl.x0f = (float)(lo[0] - wmax - 0.25 * cell); pl.z0f = (float)(lo[2] - wmax - 0.25 * cell);
-            // registration against the cell edges the KERNEL will use (fp32 origin and width), widened by eps again
-            auto cell_of = [&](double v, float origin) { return (int)std::floor((v - (double)origin) / (double)pl.cellf); };
-            const int nx = pl.nx, nz = pl.nz;
-            pl.cells.assign((size_t)nx * nz * 4, 0xffff);
-            pl.halfwidth.assign(m, 0.0);
-            std::vector<int> count((size_t)nx * nz, 0);
-            std::vector<char> is_small(m, 0);
-            for (int i : small) is_small[i] = 1;
-            for (int i = 0; i < m; ++i) {
-                if (!is_small[i]) { pl.direct.push_back(i); continue; }
-                const double cx = cr[4 * i], cy = cr[4 * i + 1], cz = cr[4 * i + 2];
-                const int ix0 = cell_of(cx - w[i] - eps, pl.x0f), ix1 = cell_of(cx + w[i] + eps, pl.x0f);
-                const int iz0 = cell_of(cz - w[i] - eps, pl.z0f), iz1 = cell_of(cz + w[i] + eps, pl.z0f);
-                bool fits = ix0 >= 0 && iz0 >= 0 && ix1 < nx && iz1 < nz;
-                for (int iz = iz0; fits && iz <= iz1; ++iz)
-                    for (int ix = ix0; ix <= ix1; ++ix) if (count[(size_t)iz * nx + ix] >= 4) fits = false;
-                if (!fits) { pl.direct.push_back(i); continue; }
-                for (int iz = iz0; iz <= iz1; ++iz)
-                    for (int ix = ix0; ix <= ix1; ++ix) { const size_t c = (size_t)iz * nx + ix; pl.cells[4 * c + count[c]++] = (uint16_t)i; }
-                ++pl.registered;
-                pl.halfwidth[i] = w[i];
-                pl.ylo = std::min(pl.ylo, cy - w[i]); pl.yhi = std::max(pl.yhi, cy + w[i]);
-                const double c3[3] = {cx, cy, cz};
-                double d2 = 0;
-                for (int k = 0; k < 3; ++k) { pl.core_lo[k] = std::min(pl.core_lo[k], c3[k]); pl.core_hi[k] = std::max(pl.core_hi[k], c3[k]); const double d = c3[k] - ctr[k]; d2 += d * d; }
-                pl.rmax_g = std::max(pl.rmax_g, radii[i]);
-                pl.cmax_g = std::max(pl.cmax_g, std::sqrt(d2));
-            }
-            // a partly filled cell pads with index m, the never-hit entry behind the table (upload_scene)
-            for (size_t c = 0; c < count.size(); ++c)
-                if (count[c] > 0) for (int k = count[c]; k < 4; ++k) pl.cells[4 * c + k] = (uint16_t)m;
-            if (pl.registered >= 16 && (!have || pl.direct.size() < best.direct.size())) { best = std::move(pl); have = true; }
-        }
-        while (!small.empty() && radii[small.back()] >= cut) small.pop_back();
-    }
-    best.usable = have && (int)best.direct.size() <= std::max(8, m / 6);
-    return best;
-}
-
-// Builds the device tables of hit_world_grid for the current scene (after build_screen_table, whose
-// recentring point the plan shares).  On return h->grid.use_grid says whether the scene has a grid.
-template <class T>
-int build_grid_tables(rtiow_handle_s* h) {
-    GridParams& g = h->grid;
-    g = GridParams{};
-    if (h->grid_blob) { HIP_TRY(h, hipFree(h->grid_blob)); h->grid_blob = nullptr; }
-    const int m = h->n;
-    const std::vector<double>& cr = h->host_cr;
-    const GridPlan best = plan_grid(m, cr, h->ctr);
-    if (!best.usable) return 0;
-    const std::vector<uint16_t>& cells = best.cells;
-    const std::vector<int>& direct = best.direct;
-    const int nx = best.nx, nz = best.nz, registered = best.registered;
-    const float cellf = best.cellf, x0f = best.x0f, z0f = best.z0f;
-    const double rfar = best.rfar, ylo = best.ylo, yhi = best.yhi, rmax_g = best.rmax_g, cmax_g = best.cmax_g;
-    const double* core_lo = best.core_lo; const double* core_hi = best.core_hi;
-    // ---- blob: cells | aos (fp32 only) | direct table | direct ids
-    const int nd = (int)direct.size(), ndp = (nd + 3) / 4 * 4;
-    std::vector<T> dtab((size_t)ndp * 4);
-    std::vector<int> ids(ndp, m);
-    for (int k = 0; k < ndp; ++k) {
-        if (k < nd) {
-            const int i = direct[k];
-            const T r = (T)cr[4 * i + 3];
-            dtab[4 * k] = (T)cr[4 * i]; dtab[4 * k + 1] = (T)cr[4 * i + 1]; dtab[4 * k + 2] = (T)cr[4 * i + 2]; dtab[4 * k + 3] = (T)(r * r);   // as upload_scene
-            ids[k] = i;
-        } else { dtab[4 * k] = dtab[4 * k + 1] = dtab[4 * k + 2] = (T)0; dtab[4 * k + 3] = (T)-1e12; }
-    }
-    if (sizeof(T) == 4) {                                    // pair-interleave like geom_a (trip_discriminants)
-        std::vector<T> pi(dtab.size());
-        for (int q = 0; q < ndp / 2; ++q)
-            for (int k = 0; k < 4; ++k) { pi[8 * q + 2 * k] = dtab[8 * q + k]; pi[8 * q + 2 * k + 1] = dtab[8 * q + 4 + k]; }
-        dtab.swap(pi);
-    }
-    std::vector<float> aos;
-    if (sizeof(T) == 4) {
-        aos.resize((size_t)(m + 1) * 4);
-        for (int i = 0; i < m; ++i) {
-            const float r = (float)cr[4 * i + 3];
-            aos[4 * i] = (float)cr[4 * i]; aos[4 * i + 1] = (float)cr[4 * i + 1]; aos[4 * i + 2] = (float)cr[4 * i + 2]; aos[4 * i + 3] = r * r;
-        }
-        aos[4 * m] = aos[4 * m + 1] = aos[4 * m + 2] = 0.0f; aos[4 * m + 3] = -1e12f;
-    }
-    auto align16 = [](size_t v) { return (v + 15) / 16 * 16; };
-    const size_t cells_bytes = align16(cells.size() * sizeof(uint16_t));
-    const size_t aos_bytes = align16(aos.size() * sizeof(float));
-    const size_t dtab_bytes = align16(dtab.size() * sizeof(T));
-    const size_t ids_bytes = align16(ids.size() * sizeof(int));
-    std::vector<unsigned char> blob(cells_bytes + aos_bytes + dtab_bytes + ids_bytes, 0);
-    std::memcpy(blob.data(), cells.data(), cells.size() * sizeof(uint16_t));
-    if (!aos.empty()) std::memcpy(blob.data() + cells_bytes, aos.data(), aos.size() * sizeof(float));
-    std::memcpy(blob.data() + cells_bytes + aos_bytes, dtab.data(), dtab.size() * sizeof(T));
-    std::memcpy(blob.data() + cells_bytes + aos_bytes + dtab_bytes, ids.data(), ids.size() * sizeof(int));
-    HIP_TRY(h, hipMalloc(&h->grid_blob, blob.size()));
-    HIP_TRY(h, hipMemcpy(h->grid_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
-    h->grid_cells_bytes = (int)cells_bytes; h->grid_aos_bytes = (int)aos_bytes; h->grid_direct_bytes = (int)dtab_bytes; h->grid_ids_bytes = (int)ids_bytes;
-    h->grid_direct = nd; h->grid_registered = registered;
-    g.use_grid = 1;
-    g.nx = nx; g.nz = nz;
-    g.x0 = x0f; g.z0 = z0f; g.cell = cellf; g.inv_cell = (float)(1.0 / (double)cellf);
-    g.ylo = std::nextafter((float)ylo, -INFINITY); g.yhi = std::nextafter((float)yhi, INFINITY);
-    g.far2 = (float)(rfar * rfar * 0.999);
-    for (int k = 0; k < 3; ++k) { g.core_lo[k] = std::nextafter((float)core_lo[k], -INFINITY); g.core_hi[k] = std::nextafter((float)core_hi[k], INFINITY); }
-    g.rmax2 = (float)(rmax_g * rmax_g * 1.0001);
-    g.cmax = (float)(cmax_g * 1.0001);
-    g.n_direct_padded = ndp;
-    g.blob = (const unsigned char*)h->grid_blob;
-    g.blob_bytes = (int)blob.size();
-    return 0;
-}
-
-template <class T>
-void fill_screen_params(RenderParams<T>& p, const rtiow_handle_s* h) {
-    p.geom_s = (const float*)h->geom_s;
-    p.use_screen = ((h->scene_source == RTIOW_SCENE_LDS || h->scene_source == RTIOW_SCENE_GRID) && h->geom_s) ? 1 : 0;
-    p.ctr_x = (T)h->ctr[0]; p.ctr_y = (T)h->ctr[1]; p.ctr_z = (T)h->ctr[2]; p.omax2 = (T)h->omax2;
-}
-
-template <class T> using RenderFn = void (*)(const RenderParams<T>);
-
-template <class T, int SRC, bool COUNT>
-RenderFn<T> pick_sched(bool persistent) {
-    return persistent ? render_persistent_kernel<T, SRC, COUNT> : render_kernel<T, SRC, COUNT>;
-}
-template <class T>
-RenderFn<T> pick_prepass_kernel(bool lds, bool count) {
-    if (lds) return count ? (RenderFn<T>)render_prepass_kernel<T, RTIOW_SCENE_LDS, true> : (RenderFn<T>)render_prepass_kernel<T, RTIOW_SCENE_LDS, false>;
-    return count ? (RenderFn<T>)render_prepass_kernel<T, RTIOW_SCENE_SCALAR, true> : (RenderFn<T>)render_prepass_kernel<T, RTIOW_SCENE_SCALAR, false>;
-}
-template <class T>
-RenderFn<T> pick_kernel(bool persistent, bool lds, bool count) {
-    if (lds) return count ? pick_sched<T, RTIOW_SCENE_LDS, true>(persistent) : pick_sched<T, RTIOW_SCENE_LDS, false>(persistent);
-    return count ? pick_sched<T, RTIOW_SCENE_SCALAR, true>(persistent) : pick_sched<T, RTIOW_SCENE_SCALAR, false>(persistent);
-}
-
-// (Re)allocates a device buffer kept in the handle when it is too small.
-template <class P>
-int ensure_buffer(rtiow_handle_s* h, P** ptr, size_t* have, size_t need) {
-    if (*ptr && *have >= need) return 0;
-    if (*ptr) { HIP_TRY(h, hipFree(*ptr)); *ptr = nullptr; *have = 0; }
-    HIP_TRY(h, hipMalloc((void**)ptr, need));
-    *have = need;
-    return 0;
-}
-
-template <class T, class CAM>
-int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_tiles, unsigned long long* seg_counter = nullptr,
-                  bool prepare_only = false) {
-    RenderParams<T> p = make_params<T>(h, cam);
-    p.cold.bx = bx; p.cold.by = by; p.cold.wave_tiles = wave_tiles;
-    p.cold.seg_counter = seg_counter ? seg_counter + 1 : nullptr;     // [0] prepass launch, [1] main (or only) launch
-    p.lane_cap = 64;
-    const bool persistent = h->schedule != RTIOW_SCHED_STATIC;
-    const int threads = bx * by;
-    // A scene whose tables do not fit the CU's LDS next to the drain scratch (several thousand
-    // spheres) is read through the scalar cache instead of failing: same image, exact loop.
-    const size_t coop_scratch = persistent ? (size_t)((threads + 63) / 64) * 64 * sizeof(CoopSlot<T>) : 0;
-    bool lds_source = h->scene_source != RTIOW_SCENE_SCALAR;
-    int effective_source = h->scene_source;
-    const bool screened = h->scene_source == RTIOW_SCENE_LDS || h->scene_source == RTIOW_SCENE_GRID;
-    if (lds_source && (sizeof(T) + (screened ? sizeof(float) : 0)) * 4 * (size_t)h->n_padded + coop_scratch > 160 * 1024) {
-        lds_source = false;
-        effective_source = RTIOW_SCENE_SCALAR;
-    }
-    if (lds_source && screened && h->screen_dirty) {
-        int rc = build_screen_table<T>(h);
-        if (rc) return rc;
-        if ((rc = build_grid_tables<T>(h))) return rc;
-    }
-    fill_screen_params<T>(p, h);
-    if (!lds_source) p.use_screen = 0;
-    size_t lds = lds_source ? sizeof(T) * 4 * (size_t)h->n_padded : 0;
-    p.screen_offset = (int)lds;
-    if (p.use_screen) lds += sizeof(float) * 4 * (size_t)h->n_padded;
-    p.cold.timeline = nullptr;                                    // set below, once the grid is known
-    // shade records ride along in LDS while a workgroup's share stays within 1/5 of the CU's LDS
-    const size_t coop_bytes = persistent ? (size_t)((threads + 63) / 64) * 64 * sizeof(CoopSlot<T>) : 0;
-    const size_t shade_bytes = (sizeof(T) * 12 * (size_t)h->n + 15) / 16 * 16;
-    p.shade_offset = (int)lds;
-    // ... and a wave's share stays under ~6.5 KB, so that LDS never caps occupancy below 6 waves/SIMD
-    const size_t waves_in_block = (size_t)((threads + 63) / 64);
-    p.shade_in_lds = (lds + shade_bytes + coop_bytes <= 32 * 1024 && (lds + shade_bytes + coop_bytes) / waves_in_block <= 6656) ? 1 : 0;
-    if (p.shade_in_lds) lds += shade_bytes;
-    p.coop_offset = (int)lds;                                // a multiple of 16
-    lds += coop_bytes;
-    // the grid blob (cells | fp32 AoS table | direct table | direct ids) goes last
-    p.grid = GridParams{};
-    p.use_grid = 0;
-    if (!seg_counter) { h->stats.grid_nx = h->stats.grid_nz = h->stats.grid_registered = h->stats.grid_direct = 0; h->stats.grid_cell = 0; }
-    if (lds_source && h->scene_source == RTIOW_SCENE_GRID && p.use_screen && h->grid.use_grid && lds + (size_t)h->grid.blob_bytes <= 160 * 1024) {
-        p.grid = h->grid;
-        p.grid.cells_offset = (int)lds;
-        p.grid.aos_offset = p.grid.cells_offset + h->grid_cells_bytes;
-        p.grid.direct_offset = p.grid.aos_offset + h->grid_aos_bytes;
-        p.grid.direct_ids_offset = p.grid.direct_offset + h->grid_direct_bytes;
-        lds += (size_t)h->grid.blob_bytes;
-        p.use_grid = 1;
-        if (!seg_counter) { h->stats.grid_nx = h->grid.nx; h->stats.grid_nz = h->grid.nz; h->stats.grid_registered = h->grid_registered; h->stats.grid_direct = h->grid_direct; h->stats.grid_cell = h->grid.cell; }
-    } else if (effective_source == RTIOW_SCENE_GRID) effective_source = RTIOW_SCENE_LDS;   // no grid for this scene: the screened loop
-    if (lds > 160 * 1024) return fail_arg(h, RTIOW_E_BADARG, "scene too large for LDS staging; use RTIOW_SCENE_SCALAR");
-    if (h->probe_n > 0) {                                    // rtiow_debug_hit_world: the tables are laid out, run hit_world on the caller's rays
-        if (!lds_source) return fail_arg(h, RTIOW_E_STATE, "rtiow_debug_hit_world needs an LDS scene source");
-        if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)hit_probe_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const int blocks = std::min(2048, (h->probe_n + 255) / 256);
-        hipLaunchKernelGGL(hit_probe_kernel<T>, dim3(blocks), dim3(256), lds, h->stream, p, (const T*)h->probe_rays, h->probe_n, (T*)h->probe_t, h->probe_idx);
-        HIP_TRY(h, hipGetLastError());
-        if (!seg_counter) h->stats.scene_source = effective_source;
-        return 0;
-    }
-    RenderFn<T> k = pick_kernel<T>(persistent, lds_source, seg_counter != nullptr);
-    if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipFuncAttributes fa{};
-    HIP_TRY(h, hipFuncGetAttributes(&fa, (const void*)k));
-    dim3 grid, block(threads);
-    int phases = 1;
-    if (persistent) {
-        if (!h->work_counter) HIP_TRY(h, hipMalloc((void**)&h->work_counter, 2 * sizeof(unsigned int)));
-        HIP_TRY(h, hipMemsetAsync(h->work_counter, 0, 2 * sizeof(unsigned int), h->stream));
-        int per_cu = 0;
-        HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, threads, lds));
-        if (per_cu < 1) per_cu = 1;
-        const int waves_per_block = (threads + 63) / 64;
-        if (h->waves_per_simd > 0) {                       // knob: fewer resident waves, more pixels per lane
-            const int cap = (h->waves_per_simd * 4 + waves_per_block - 1) / waves_per_block;
-            if (cap < per_cu) per_cu = cap;
-        }
-        const long long tile_slots = (long long)((p.cold.W + 7) / 8) * ((h->local_rows + 7) / 8) * POOL;
-        // Underfilled launch (fewer 64-pixel pools than resident waves: small frames): let only the first
-        // `lane_cap` lanes of every wave take pixels.  More waves are busy, each permanently in the
-        // cooperative mode, where its idle lanes split the sphere loops of the live ones: a trip gets
-        // shorter, and with so little work the frame is as long as its longest chain of trips.
-        // Measured (profiles/r01_lane_cap_sweep.txt): scene 1 320x192x10 2.27 -> 1.06 ms, 640x384x100
-        // 19.4 -> 17.0 ms; frames with at least one pool per wave are unchanged (cap 64).
-        int lane_cap = 64;
-        {
-            const long long pools = tile_slots / POOL, waves = (long long)h->num_cus * per_cu * waves_per_block;
-            while (lane_cap > 16 && pools * (64 / lane_cap) < waves) lane_cap >>= 1;  // the largest share that keeps every wave busy; not below 16 (with the grid walk 8-lane waves lose: scene 1 320x192x100 6.85 vs 5.96 ms, profiles/r02_lane_cap_sweep.jsonl)
-#ifdef RTIOW_TUNING
-            if (const char* e = std::getenv("RTIOW_TUNE_LANE_CAP")) lane_cap = std::atoi(e);
-#endif
-        }
-        p.lane_cap = lane_cap;
-        long long blocks = (long long)h->num_cus * per_cu;
-        const long long per_block = (long long)waves_per_block * lane_cap;
-        const long long useful = (tile_slots + per_block - 1) / per_block;
-        if (blocks > useful) blocks = useful;               // never more waves than lane_cap-pixel shares of the pools
-        grid = dim3((unsigned)blocks);
-
-        const int npix = p.cold.W * h->local_rows;
-        const int S = p.cold.S;
-        // prepass length: enough samples to rank the pixels, a small share of the frame
-        int SA = S >= 64 ? 3 : (S >= 24 ? 2 : 0);
-#ifdef RTIOW_TUNING
-        if (const char* e = std::getenv("RTIOW_TUNE_SA")) SA = std::atoi(e);          // tuning build only (scripts/tune_sweep.py)
-#endif   // measured on the headline config: 1 -> 25.5 ms, 2 -> 22.5, 3 -> 22.1, 4 -> 22.4, 8 -> 23.1
-        p.cold.work_counter = h->work_counter;
-        p.cold.s_begin = 0; p.s_end = S; p.cold.rng_in = h->rng; p.cold.mid_in = nullptr; p.cold.mid_out = nullptr;
-        p.cold.cost_out = nullptr; p.cold.order = nullptr; p.cold.total_slots = (int)tile_slots; p.cold.first_pools = 0;
-        p.cold.solo_waves = 0; p.cold.solo_lanes = 1;
-        if (h->schedule == RTIOW_SCHED_SORTED && SA > 0 && npix >= 4096) {
-            phases = 2;
-            const int total_pools = (npix + POOL - 1) / POOL;
-            int rc;
-            if ((rc = ensure_buffer(h, &h->mid, &h->mid_bytes, (size_t)npix * sizeof(MidState<T>)))) return rc;
-            if ((rc = ensure_buffer(h, &h->cost, &h->cost_bytes, (size_t)npix * sizeof(uint32_t)))) return rc;
-            if ((rc = ensure_buffer(h, &h->cost_rank, &h->cost_rank_bytes, (size_t)npix * sizeof(uint32_t)))) return rc;
-            // Solo waves (ColdParams::solo_*, render_solo_kernel).  A shard or small frame ends with its longest sample
-            // chains (one pixel = one sequential chain), and a chain advances at the pace of its wave: 2452 segments at
-            // ~3 us per trip among 63 other pixels.  Two heavy pixels alone in a wave share every sphere loop with the
-            // idle lanes and skip the divergent work of wave-mates.  Which pixels: the top of the cost ranking.  How
-            // many waves: more than ~5 % of the resident waves cost more throughput than the chains gain; measured per
-            // fill level (profiles/r02_handout_study/): 1/8 frame 6.96 -> 5.65 ms with 128 waves (5.78 with 256),
-            // 1/4 frame 7.85 -> 6.61 with 256 (7.03 with 128), 1/2 frame 8.43 -> 8.21, 1280x720 8.82 -> 8.34; the full
-            // frame (6.3 pools per wave) loses 1-2 % and keeps the plain kernel.  Outlier chains need a bounce limit
-            // that lets rare long paths exist: at 10 bounces the solo waves cost 4-11 % on both scenes, at 25 scene 3
-            // gains 9 % and scene 1 -- the reference's own benchmark grid -- loses 2-5 %, from 50 on both gain
-            // (sweep6_bounce_limit.txt): the rule asks for more than 32.
-            const double fill_level = (double)total_pools / (double)(blocks * waves_per_block);
-            int solo_waves = (seg_counter || p.B < 32) ? 0 : (fill_level < 1.2 ? 128 : (fill_level < 4.0 ? 256 : 0)), solo_lanes = 2;
-#ifdef RTIOW_TUNING
-            if (const char* e = std::getenv("RTIOW_TUNE_SOLO_WAVES")) solo_waves = std::atoi(e);
-            if (const char* e = std::getenv("RTIOW_TUNE_SOLO_LANES")) solo_lanes = std::atoi(e);
-#endif
-            if (solo_lanes < 1) solo_lanes = 1;
-            RenderFn<T> k_solo = lds_source ? (RenderFn<T>)render_solo_kernel<T, RTIOW_SCENE_LDS> : (RenderFn<T>)render_solo_kernel<T, RTIOW_SCENE_SCALAR>;
-            if (solo_waves > 0) {
-                if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)k_solo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                int per_cu_solo = 0;
-                HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_solo, (const void*)k_solo, threads, lds));
-                if ((long long)per_cu_solo * h->num_cus < blocks) solo_waves = 0;   // its workgroups must all be resident, as the first pools assume
-            }
-            if (solo_lanes > lane_cap) solo_lanes = lane_cap;
-            if (solo_waves > (int)blocks) solo_waves = (int)blocks;
-            if ((long long)solo_waves * solo_lanes > npix / 2) solo_waves = npix / 2 / solo_lanes;
-            const int solo_slots = solo_waves * solo_lanes;
-            if ((rc = ensure_buffer(h, &h->order, &h->order_bytes, ((size_t)total_pools * POOL + (size_t)solo_slots) * sizeof(int)))) return rc;
-            if ((rc = ensure_buffer(h, &h->sort_scratch, &h->sort_scratch_bytes, (size_t)3 * COST_BINS * sizeof(unsigned)))) return rc;
-            if (prepare_only) return 0;                  // every table and buffer of this configuration now exists
-            // ---- prepass: samples [0, SA) in tile order through the same persistent body (the static
-            // kernel keeps only ~40 % of its lanes busy over a few samples: 2.6 ms vs 1.4 ms measured
-            // for 4 samples); RNG state, colour sum and segment count are parked per pixel.
-            RenderParams<T> pa = p;
-            pa.s_end = SA; pa.cold.mid_out = h->mid; pa.cold.cost_out = h->cost;
-            pa.cold.seg_counter = seg_counter;
-            RenderFn<T> kp = pick_prepass_kernel<T>(lds_source, seg_counter != nullptr);
-            if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kp, grid, block, lds, h->stream, pa);
-            if (h->time_phases) HIP_TRY(h, hipEventRecord(h->ev_a, h->stream));
-            h->stats.prepass_samples = SA;
-            HIP_TRY(h, hipGetLastError());
-            // ---- rank the pixels by measured cost, heavy first, dealt into balanced pools.
-            // Blocks of the order are one "age class" of resident waves wide (see first_pools).
-            unsigned* hist = h->sort_scratch; unsigned* start = hist + COST_BINS; unsigned* fill = start + COST_BINS;
-            HIP_TRY(h, hipMemsetAsync(hist, 0, COST_BINS * sizeof(unsigned), h->stream));
-            HIP_TRY(h, hipMemsetAsync(h->order, 0xff, ((size_t)total_pools * POOL + (size_t)solo_slots) * sizeof(int), h->stream));
-            const int sort_blocks = (npix + 255) / 256;
-            const uint32_t* rank_by = h->cost;
-            int smooth_hw = 6;                          // 13 x 13 window: profiles/r02_cost_smoothing_sweep.jsonl
-#ifdef RTIOW_TUNING
-            if (const char* e = std::getenv("RTIOW_TUNE_SMOOTH")) smooth_hw = std::atoi(e);
-#endif
-            if (smooth_hw > 0) {
-                if (smooth_hw > 24) smooth_hw = 24;      // 2 x (tile + halo) words of LDS: 37 KB at 24
-                const int smooth_blocks = ((p.cold.W + SMOOTH_TW - 1) / SMOOTH_TW) * ((h->local_rows + SMOOTH_TH - 1) / SMOOTH_TH);
-                const size_t smooth_lds_bytes = ((size_t)(SMOOTH_TW + 2 * smooth_hw) + SMOOTH_TW) * (size_t)(SMOOTH_TH + 2 * smooth_hw) * sizeof(uint32_t);
-                // one rank: its strips are adjacent in the image, the window may cross them (it did not before: 13 x <= 8 rows)
-                int window_strip = h->nranks == 1 ? (h->local_rows > 0 ? h->local_rows : 1) : h->strip_rows;
-#ifdef RTIOW_TUNING
-                if (const char* e = std::getenv("RTIOW_TUNE_SMOOTH_STRIP")) window_strip = std::atoi(e) > 0 ? std::atoi(e) : (h->local_rows > 0 ? h->local_rows : 1);
-#endif
-                hipLaunchKernelGGL(cost_smooth_kernel, dim3(smooth_blocks), dim3(256), smooth_lds_bytes, h->stream, h->cost, h->cost_rank, p.cold.W, h->local_rows, window_strip, smooth_hw, hist);
-                rank_by = h->cost_rank;
-            } else {
-                hipLaunchKernelGGL(cost_hist_kernel, dim3(sort_blocks < 1024 ? sort_blocks : 1024), dim3(256), 0, h->stream, rank_by, npix, hist);
-            }
-            hipLaunchKernelGGL(cost_scan_kernel, dim3(1), dim3(COST_BINS), 0, h->stream, hist, start, fill);
-            const int resident_waves = (int)blocks * waves_per_block;
-            const int age_classes = (int)((blocks + h->num_cus - 1) / h->num_cus);
-            int pools_per_block = (resident_waves + age_classes - 1) / age_classes;
-            if (pools_per_block > total_pools) pools_per_block = total_pools;
-            // Deal granularity: `deal_group` consecutive ranks (= neighbouring pixels of equal cost) stay
-            // in one pool, the groups go round-robin over the block's pools.  Coherent groups mean fewer
-            // distinct spheres pass the screen per wave (8.9 exact blocks per wave-iteration with single
-            // ranks vs 3.6 in tile order); mixed costs in a pool let a heavy pixel finish in the fast
-            // cooperative mode, which is what small shards need.  Measured (profiles/r01_deal_group_sweep.txt):
-            // full frame 24.1 -> 22.5 ms with 16-32, half frame 14.7 -> 14.0 with 8, quarter and eighth
-            // frames are fastest with 1.
-            const double pools_per_wave = (double)total_pools / (double)resident_waves;
-            // With the grid walk (a lane's cost follows ITS ray) coherence pays more: whole pools of 64 neighbouring
-            // ranks, 15.3 -> 14.7 ms on the full frame (profiles/r02_tune_sweep.jsonl) and, once the ranks come from
-            // the smoothed cost, on every frame with at least 2.5 pools per wave (1280x720: 9.3 ms with groups of 1,
-            // 11.4 with 8, 8.7 with 64; profiles/r02_cost_smoothing_sweep.jsonl); smaller shards keep single ranks.
-            int deal_group = pools_per_wave >= 2.5 ? 64 : 1;
-#ifdef RTIOW_TUNING
-            if (const char* e = std::getenv("RTIOW_TUNE_DEAL")) deal_group = std::atoi(e);
-#endif
-            const int scatter_blocks = ((p.cold.W + 63) / 64) * ((h->local_rows + 63) / 64);   // one per 64 x 64 super-tile
-            hipLaunchKernelGGL(cost_scatter_kernel, dim3(scatter_blocks), dim3(1024), 0, h->stream, rank_by, p.cold.W, h->local_rows, start, fill, h->order,
-                               pools_per_block, total_pools, deal_group, solo_slots);
-            HIP_TRY(h, hipGetLastError());
-            // ---- main launch: samples [SA, S) in that order
-            p.cold.s_begin = SA; p.cold.mid_in = h->mid; p.cold.order = h->order;
-            p.cold.total_slots = solo_slots + total_pools * POOL;
-            p.cold.work_counter = h->work_counter + 1;
-            p.cold.first_pools = 1;
-            p.cold.solo_waves = solo_waves; p.cold.solo_lanes = solo_lanes;
-            if (solo_waves > 0) {
-                k = k_solo;
-                HIP_TRY(h, hipFuncGetAttributes(&fa, (const void*)k));
-            }
-            const unsigned counter_start = (unsigned)solo_slots + (unsigned)(resident_waves - solo_waves) * (unsigned)lane_cap;
-            HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)(h->work_counter + 1), (int)counter_start, 1, h->stream));
-        }
-    } else {
-        grid = dim3((p.cold.W + bx - 1) / bx, (h->local_rows + by - 1) / by);
-        p.cold.s_begin = 0; p.s_end = p.cold.S; p.cold.rng_in = h->rng; p.cold.mid_in = nullptr; p.cold.mid_out = nullptr;
-        p.cold.cost_out = nullptr; p.cold.order = nullptr; p.cold.total_slots = 0; p.cold.first_pools = 0; p.cold.work_counter = nullptr;
-        p.cold.solo_waves = 0; p.cold.solo_lanes = 1;
-    }
-    if (prepare_only) return 0;
-    if (seg_counter) {
-        h->last_count_blocks = (int)(grid.x * grid.y);
-        h->last_count_waves_per_block = (threads + 63) / 64;
-        // the kernel writes 8 words per wave: hand the buffer over only if it holds every wave of this launch
-        if (h->timeline && (size_t)h->last_count_blocks * h->last_count_waves_per_block <= h->timeline_cap_waves) p.cold.timeline = h->timeline;
-    }
-    if (h->time_phases && phases == 2) HIP_TRY(h, hipEventRecord(h->ev_b, h->stream));
-    hipLaunchKernelGGL(k, grid, block, lds, h->stream, p);
-    HIP_TRY(h, hipGetLastError());
-    if (!seg_counter) {
-        h->stats.vgprs = fa.numRegs;
-        h->stats.sgprs = 0;
-        h->stats.lds_bytes = (int)(lds + fa.sharedSizeBytes);
-        h->stats.block_x = bx; h->stats.block_y = by;
-        h->stats.scene_source = effective_source;
-        h->stats.schedule = h->schedule;
-        h->stats.grid_blocks = (int)(grid.x * grid.y);
-        h->stats.phases = phases;
-        if (phases == 1) h->stats.prepass_samples = 0;
-        h->stats.solo_waves = phases == 2 ? p.cold.solo_waves : 0;
-        h->stats.solo_lanes = phases == 2 && p.cold.solo_waves > 0 ? p.cold.solo_lanes : 0;
-    }
-    return 0;
-}
-
-// T (the reference's --threads) shapes the workgroup of RTIOW_SCHED_STATIC, whose lanes ARE the
-// pixels of a T x T block.  The dynamic schedules hand pixels to lanes themselves, so a workgroup
-// there is just four waves whatever T says (measured with T as the workgroup size: 69 / 22.3 / 22.3 /
-// 33 / 26 ms for T = 4 / 8 / 16 / 24 / 32 -- partly filled waves and uneven SIMD packing).
-void block_shape(int T, bool static_schedule, int& bx, int& by, int& wave_tiles) {
-    if (!static_schedule) T = 0;
-    if (T == 0) { bx = 16; by = 16; wave_tiles = 1; }       // library tiling: 4 waves, each an 8x8 tile
-    else if (T == 8) { bx = 8; by = 8; wave_tiles = 1; }    // == the reference's 8x8 block (one wave)
-    else { bx = T; by = T; wave_tiles = 0; }                 // the reference's T x T row-major block
-}
-
-}  // namespace
+#include "device/xorwow.h"
+#include "device/params.h"
+#include "device/probes.h"
+#include "device/vecmath.h"
+#include "device/sampling.h"
+#include "device/roots.h"
+#include "device/hit_loop.h"
+#include "device/hit_grid.h"
+#include "device/shade.h"
+#include "device/hit_coop.h"
+#include "device/pixel_io.h"
+#include "device/render_kernels.h"
+#include "device/cost_sort.h"
+#include "library/xorwow_jump.h"
+#include "library/handle.h"
+#include "library/scene_tables.h"
+#include "library/launch.h"
 
 extern "C" {
 

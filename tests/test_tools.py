@@ -115,35 +115,3 @@ def test_benchmark_script_writes_reference_csv_schema(native):
     text = open(os.path.join(ROOT, "tools", "hip_benchmark.sh")).read()
     assert "scene_id,width,height,samples,bounces,threads,run,render_only_time_ms,end_to_end_time_ms" in text
     assert subprocess.run(["bash", "-n", os.path.join(ROOT, "tools", "hip_benchmark.sh")]).returncode == 0
-
-
-def test_ppm_diff_dirs_batches_pairs_like_the_reference_script(native, tmp_path):
-    """tools/ppm_diff_dirs.sh == timing-benchmarks/ppm_diff.sh: pairs by age, float_double_diff_<name>, usage/error exits;
-    plus the tolerance gate (exit 2)."""
-    import time
-    script = os.path.join(ROOT, "tools", "ppm_diff_dirs.sh")
-    d1, d2, out = tmp_path / "float", tmp_path / "double", tmp_path / "diff"
-    d1.mkdir(); d2.mkdir()
-    rng = np.random.default_rng(3)
-    imgs = [rng.uniform(0, 1, (6, 8, 3)).astype(np.float32) for _ in range(2)]
-    for k, img in enumerate(imgs):
-        native.write_ppm(str(d1 / ("global_float_scene%d.ppm" % k)), img)
-        time.sleep(0.02)
-    for k, img in enumerate(imgs):
-        native.write_ppm(str(d2 / ("global_double_scene%d.ppm" % k)), np.clip(img + (0.02 if k == 1 else 0.0), 0, 1).astype(np.float64))
-        time.sleep(0.02)
-    r = subprocess.run(["bash", script, str(d1), str(d2), str(out)], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
-    assert "Found 2 pairs of files to process." in r.stdout and "Warning: Filenames do not match" in r.stdout
-    assert sorted(os.listdir(str(out))) == ["float_double_diff_global_float_scene0.ppm", "float_double_diff_global_float_scene1.ppm"]
-    assert open(str(out / "float_double_diff_global_float_scene0.ppm")).read().split()[4:] == ["0"] * (6 * 8 * 3)
-    # gate: the second pair differs by ~5 levels
-    r = subprocess.run(["bash", script, str(d1), str(d2), str(out), "--max-mean", "1.0"], capture_output=True, text=True)
-    assert r.returncode == 2 and "failed for pair 'global_float_scene1.ppm'" in r.stdout
-    # usage and error paths
-    assert subprocess.run(["bash", script, str(d1)], capture_output=True, text=True).returncode == 1
-    r = subprocess.run(["bash", script, str(d1), str(tmp_path / "nope"), str(out)], capture_output=True, text=True)
-    assert r.returncode == 1 and "not found" in r.stdout
-    (d2 / "extra.ppm").write_text("P3\n1 1\n255\n0 0 0\n")
-    r = subprocess.run(["bash", script, str(d1), str(d2), str(out)], capture_output=True, text=True)
-    assert r.returncode == 1 and "do not match" in r.stdout
