@@ -4,31 +4,41 @@
 Metric (BASELINE.json): Mrays/s = W x H x samples / render time, on
 scene 3 (125 spheres, the reference's default: branch), 1920x1080, 100 spp, 50 bounces, fp32.
 One "step" = one full render of the frame (for N GPUs: every rank renders its interleaved
-row strips, then one RCCL gather of the strips to rank 0 -- the gather is inside the step).
+row strips, then ONE exchange of the strips to rank 0 -- the exchange is inside the step).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W]                                  (a)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...        (b)
+
+(a) without a launcher: N = 1 is the plain single-handle path; N > 1 drives the N GPUs of the node from THIS
+    process through the library's own group (rtiow_group_*, csrc/rtiow_group.hip: one handle, stream and launch
+    per device, then ncclSend/ncclRecv to device 0 over xGMI -- RCCL, loaded by the library -- or peer copies).
+    `--devices a,b,..` lists the device of every rank; a device may repeat (ranks then share it: how the N-rank
+    path is exercised on a one-GPU box).
+(b) under torch.distributed.run (RANK/WORLD_SIZE/MASTER_* in the environment): one process per GPU, backend
+    "nccl" (= RCCL), the strips gathered with torch.distributed.  Distributed even at WORLD_SIZE=1: process group,
+    gather, all_reduce and barriers all execute.
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline      dominant kernel = the main launch of the render (render_persistent_kernel; the
-                sorted schedule's prepass of 3 of the 100 samples is a separate, named launch)
-                against the VALU peak: algorithmic flops of that launch = segments*(23*N+120) +
-                rays*60 (segments counted per launch on the device by
-                rtiow_count_segments) / its mean HIP-event time over the timed steps.  The same
-                figures for the whole step (all launches) are under "step".
-  cpu_baseline  the reference's serial tracer (oracle/_ref, built from the reference's own
-                sources) or, if absent, the oracle's serial port, timed on this host (1 thread)
-                on a bounded sample of the same workload; "config1" inside it is BASELINE.json
-                configs[0] in full (serial CPU, scene 1, 320x192, 10 spp, 25 bounces)
-  scaling       what bounds strong scaling of this path: a pixel's samples are ONE
-                sequential RNG chain, so no rank finishes before prepass + its longest chain x
-                the latency of a lone ray's trip: "floor_ms" (measured here: the longest chain is
-                counted on the device, the trip latency is timed on a 1-pixel frame); per-rank
-                kernel_ms and gather_ms (events around the collective) when the run is distributed
-
-Launched by torch.distributed.run (RANK/WORLD_SIZE in the environment) the run is distributed
-even at WORLD_SIZE=1: process group "nccl" (= RCCL), the strip gather, the all_reduce of the
-timings and the barriers all execute, so the N>1 code path can be exercised on a one-GPU box.
+  roofline      dominant kernel = the main launch of the render (render_persistent_kernel; the sorted schedule's
+                prepass of 3 of the 100 samples is a separate, named launch) against the VECTOR-ALU ISSUE peak:
+                `achieved` = SQ_INSTS_VALU wave-instructions of that launch x 64 lanes x 2 flop (one FMA issue slot
+                each) / its mean HIP-event time; `peak` 157.3 TFLOP/s = one wave64 instruction per 2 cycles per
+                SIMD-32; `frac` = achieved / peak = the share of the chip's vector issue slots the launch fills --
+                EXECUTED work.  The counters come from rocprofv3 --pmc passes run by this very bench.py (child
+                processes over the same library, before this process touches the GPU; `--pmc live`, default at
+                N = 1) or from the committed record under profiles/ -- used only when its build id equals
+                rtiow_build_id() of the loaded library (SHA-256 of sources + flags); otherwise null, never a stale
+                number.  `algorithmic_TFLOPs` / `algorithmic_frac` = the reference's own arithmetic served per
+                second: segments x (23 flop x every sphere + 120) + rays x 60 -- comparable work,
+                not executed work (the grid walk tests a few spheres per segment), so it may exceed the peak.
+                `traffic` = HBM bytes of the launch from the FETCH_SIZE / WRITE_SIZE passes (separate passes, gfx950
+                x2 fetch correction as an upper bound), against `algorithmic_hbm_bytes_per_launch`.
+  cpu_baseline  the reference's serial tracer (oracle/_ref, built from the reference's own sources) or, if absent,
+                the oracle's serial port, timed on this host (1 thread) on a bounded sample of the same workload;
+                "config1" inside it is BASELINE.json configs[0] in full
+  scaling_detail  what bounds strong scaling of this path: a pixel's samples are ONE sequential RNG
+                chain, so no rank finishes before prepass + its longest chain x the latency of a lone ray's trip:
+                "floor_ms"; per-rank kernel_ms and the time of the exchange
 """
 import argparse
 import json
@@ -39,14 +49,14 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
-VALU_FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz
-VALU_FP64_PEAK_TFLOPS = 78.6
+VALU_FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz = one wave64 FMA per 2 cycles per SIMD
+VALU_FP64_PEAK_TFLOPS = 78.6      # v_fma_f64: half that rate (one wave64 instruction per 4 cycles)
 HBM_PEAK_GBS = 8000.0
+PMC_RECORDS = os.path.join(ROOT, "profiles", "pmc_records.json")
 
 
 def parse():
@@ -64,6 +74,11 @@ def parse():
     ap.add_argument("--scene_source", default="grid", choices=("grid", "lds", "scalar", "lds_exact"))
     ap.add_argument("--schedule", default="sorted", choices=("sorted", "persistent", "static"))
     ap.add_argument("--strip_rows", type=int, default=0, help="rows per interleaved strip; 0 = 8 for N <= 2, 2 for N >= 4 (profiles/r01_strip_rows_sweep.txt)")
+    ap.add_argument("--devices", default="", help="without a launcher: the device of every rank, e.g. 0,1,2,3 (default 0..N-1); a device may repeat")
+    ap.add_argument("--gather", default="auto", choices=("auto", "rccl", "peer"), help="transport of the in-library group (without a launcher, N > 1)")
+    ap.add_argument("--pmc", default="auto", choices=("auto", "live", "committed", "off"),
+                    help="where roofline.frac's counters come from: rocprofv3 --pmc passes run now (live), the committed record if it matches "
+                         "the loaded build (committed), neither (off); auto = live at N = 1, falling back to committed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scaling-probe", action="store_true",
                     help="skip the 1-pixel lone-ray probe (it launches the main kernel by the same name: keeps rocprofv3 --stats averages clean)")
@@ -127,34 +142,35 @@ def cpu_baseline_config1():
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": what + "; oracle serial port", "seconds": dt}
 
 
-def pmc_traffic(args):
-    """HBM bytes of the main render launch from the committed rocprofv3 --pmc passes (profiles/traffic.json):
-    (total with the gfx950 x2 FETCH correction, fetch bytes raw, write bytes), or (None, None, None)."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(path):
-        return None, None, None
-    key = "s%d_%dx%d_%dspp_%db_f%d" % (args.scene_id, args.width, args.height, args.samples, args.bounces, args.precision)
-    e = json.load(open(path)).get(key, {})
-    f, w = e.get("main_launch_FETCH_SIZE_KB"), e.get("main_launch_WRITE_SIZE_KB")
-    return (e.get("hbm_bytes_main_launch", e.get("hbm_bytes_per_launch")), f * 1024.0 if f is not None else None, w * 1024.0 if w is not None else None)
+def pmc_config(args):
+    return {"scene_id": args.scene_id, "width": args.width, "height": args.height, "samples": args.samples, "bounces": args.bounces,
+            "precision": args.precision, "schedule": args.schedule, "scene_source": args.scene_source, "threads": args.threads}
 
 
-def pmc_issue(args):
-    """Vector-instruction issue of the main launch from the committed rocprofv3 --pmc passes (the newest
-    profiles/r*_pmc_sq_final.json; headline configuration only): wave-instructions per launch and SIMD cycles per
-    instruction.  A wave64 VALU instruction occupies a SIMD-32 for at least 2 cycles, so 2 / cycles-per-
-    instruction is the fraction of the vector issue peak the launch reaches."""
-    import glob
-    if (args.scene_id, args.width, args.height, args.samples, args.bounces, args.precision, args.schedule, args.scene_source) != (3, 1920, 1080, 100, 50, 32, "sorted", "grid"):
-        return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_final.json")))
-    if not files:
-        return None
-    d = json.load(open(files[-1])).get("counters", {}).get("derived_main")
-    if not d:
-        return None
-    return {"valu_wave_insts_per_launch": d["valu_insts_per_launch"], "simd_cycles_per_valu_inst": round(d["simd_cycles_per_valu_inst"], 3),
-            "valu_issue_frac": round(2.0 / d["simd_cycles_per_valu_inst"], 4), "source": os.path.relpath(files[-1], ROOT)}
+def under_a_profiler():
+    """bench.py itself running below rocprofv3 (scripts/refresh_profiles.sh): no nested profiler children."""
+    return any(k.startswith("ROCPROFILER_") or k.startswith("ROCP_") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+
+
+def pmc_live(args):
+    """The rocprofv3 --pmc passes of this configuration, run NOW as child processes over the library this bench is
+    about to load (must be called before this process initialises the GPU).  Returns (record | None, note)."""
+    import pmc_passes
+    try:
+        rec = pmc_passes.collect(pmc_config(args), reps=2, timeout=420)
+    except Exception as e:                       # no rocprofv3, no permission, a failing pass: the bench line still prints
+        return None, "live passes failed: %s" % str(e)[:300]
+    return rec, "rocprofv3 --pmc child processes of this bench.py run (scripts/pmc_passes.py), %s" % ", ".join(
+        "%s %.1f s" % (p["cmd"].split("--pmc ")[1].split()[0], p["seconds"]) for p in rec["passes"])
+
+
+def pmc_committed(args, build_id):
+    import pmc_passes
+    key = pmc_passes.config_key(args.scene_id, args.width, args.height, args.samples, args.bounces, args.precision, args.schedule, args.scene_source)
+    rec = pmc_passes.load_record(PMC_RECORDS, key, build_id)
+    if rec is None:
+        return None, "no record for %s taken on build %s... in %s" % (key, build_id[:12], os.path.relpath(PMC_RECORDS, ROOT))
+    return rec, "committed record %s[%s], build id matches the loaded library" % (os.path.relpath(PMC_RECORDS, ROOT), key)
 
 
 def lone_ray_trip_us(rt, device_index, prec, scene, args):
@@ -171,28 +187,184 @@ def lone_ray_trip_us(rt, device_index, prec, scene, args):
     return (best * 1e3 / segs if segs else None), segs
 
 
-def main():
-    args = parse()
-    # The driver reads ONE JSON line from stdout; libraries are chatty there (RCCL prints a version
-    # banner on stdout when its first communicator is created).  Everything but that line goes to stderr.
+SOURCES = {"grid": "SCENE_GRID", "lds": "SCENE_LDS", "scalar": "SCENE_SCALAR", "lds_exact": "SCENE_LDS_EXACT"}
+SCHEDULES = {"sorted": "SCHED_SORTED", "persistent": "SCHED_PERSISTENT", "static": "SCHED_STATIC"}
+
+
+def roofline_object(args, st, segments_main_rank0, main_ms, pmc, pmc_note, world):
+    """The dominant kernel (rank 0's main launch) against the vector-issue peak; see the module docstring."""
+    prec, S = args.precision, args.samples
+    nspheres = st["num_spheres"]
+    my_rays = float(st["primary_rays"])
+    per_seg = 23.0 * nspheres + 120.0
+    peak = VALU_FP32_PEAK_TFLOPS if prec == 32 else VALU_FP64_PEAK_TFLOPS
+    rays_main = my_rays * (S - st["prepass_samples"]) / S
+    flops = float(segments_main_rank0) * per_seg + rays_main * 60.0       # the main launch alone
+    mms = float(np.mean(main_ms))
+    algorithmic = flops / (mms * 1e-3) / 1e12
+    # algorithmic HBM bytes of the main launch, per pixel: the framebuffer write (3 T) + its starting state:
+    # the 48/64-byte hand-over record and a 4-byte order entry (sorted schedule) or the 24-byte RNG state
+    my_pixels = my_rays / S
+    state_bytes = ((48 if prec == 32 else 64) + 4) if st["phases"] == 2 else 24
+    fb_bytes = my_pixels * (3 * (4 if prec == 32 else 8) + state_bytes)
+    achieved = frac = traffic = fetch_b = write_b = None
+    issued = None
+    if pmc is not None and world == 1:
+        import pmc_passes
+        main = pmc["counters"].get("main", {})
+        d = pmc_passes.derive(main, launch_ms=mms)
+        if d.get("valu_wave_insts_per_launch"):
+            # one FMA issue slot = 64 lanes x 2 flop; fp64 FMA slots are half as many per second (peak above)
+            achieved = d["valu_wave_insts_per_launch"] * 128.0 / (mms * 1e-3) / 1e12 * (1.0 if prec == 32 else 0.5)
+            frac = achieved / peak
+            issued = {"valu_wave_insts_per_launch": d["valu_wave_insts_per_launch"],
+                      "valu_issue_frac": round(d["valu_issue_frac"], 4),
+                      "simd_cycles_per_valu_inst_profiled": round(d["simd_cycles_per_valu_inst"], 3) if "simd_cycles_per_valu_inst" in d else None,
+                      "valu_issue_frac_at_profiled_clock": round(d["valu_issue_frac_at_profiled_clock"], 4) if "valu_issue_frac_at_profiled_clock" in d else None,
+                      "active_lane_frac": round(d["active_lane_frac"], 4) if "active_lane_frac" in d else None,
+                      "salu_insts_per_launch": main.get("SQ_INSTS_SALU"),
+                      "wave_cycles_split": {k: main.get(k) for k in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU") if main.get(k)},
+                      "prepass_valu_wave_insts": pmc["counters"].get("prepass", {}).get("SQ_INSTS_VALU")}
+        t = pmc.get("traffic_main")
+        if t:
+            traffic, fetch_b, write_b = t["hbm_bytes"], t["fetch_bytes_raw"], t["write_bytes"]
+    kernel = {"static": "render_kernel", "persistent": "render_persistent_kernel", "sorted": "render_solo_kernel" if st["solo_waves"] else "render_persistent_kernel"}[args.schedule]
+    return {"bound": "valu", "achieved": round(achieved, 3) if achieved is not None else None, "peak": peak, "unit": "TFLOP/s",
+            "frac": round(frac, 4) if frac is not None else None, "traffic": traffic,
+            "achieved_is": "EXECUTED vector issue: SQ_INSTS_VALU wave-instructions of the main launch x 64 lanes x 2 flop (one FMA slot each) / launch time; "
+                           "frac = share of the SIMD-32 issue slots filled (a wave64 VALU instruction takes 2 cycles; fp64: 4). null: no counters for THIS build",
+            "counters_from": pmc_note, "build_id": pmc.get("build_id") if pmc else None, "issued": issued,
+            "algorithmic_TFLOPs": round(algorithmic, 3), "algorithmic_frac": round(algorithmic / peak, 4),
+            "algorithmic_is": "the reference's own sphere loop served per second: 23 flop x every sphere x every segment + 120 per segment + 60 per ray "
+                              "(SURVEY.md 8d); the grid walk finds the same hits testing a few spheres per segment, so this is comparable work, not executed work",
+            "fetch_bytes": fetch_b, "write_bytes": write_b,   # raw FETCH_SIZE / WRITE_SIZE of the main launch
+            "kernel": "%s<%s>" % (kernel, "float" if prec == 32 else "double"),
+            "launch_ms_mean": round(mms, 4), "launch_ms_min": round(float(np.min(main_ms)), 4),
+            "algorithmic_flops_per_launch": flops, "segments_in_launch": int(segments_main_rank0),
+            "samples_in_launch": int(S - st["prepass_samples"]),
+            "algorithmic_hbm_bytes_per_launch": fb_bytes,
+            "hbm_achieved_GBps": round((traffic if traffic else fb_bytes) / (mms * 1e-3) / 1e9, 3), "hbm_peak_GBps": HBM_PEAK_GBS}
+
+
+def emit(json_fd, args, ctx):
+    """Rank 0: the contract line."""
+    W, H, S, B, prec = args.width, args.height, args.samples, args.bounces, args.precision
+    st = ctx["stats0"]
+    rays = float(W) * H * S
+    ms_per_step = ctx["elapsed"] / args.steps * 1e3
+    value = rays / (ms_per_step * 1e-3) / 1e6
+    kms = float(np.mean(ctx["kernel_ms"]))
+    per_seg = 23.0 * st["num_spheres"] + 120.0
+    flops_step = float(ctx["segments0"]) * per_seg + float(st["primary_rays"]) * 60.0
+    peak = VALU_FP32_PEAK_TFLOPS if prec == 32 else VALU_FP64_PEAK_TFLOPS
+    world = ctx["world"]
+    line = {
+        "metric": "Mrays/s (= W x H x samples / render time)",
+        "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32" if prec == 32 else "f64", "data": "synthetic",
+        "config": {"workload": "scene %d (%d spheres), %dx%d, %d spp, %d bounces, XORWOW seed 1227" % (args.scene_id, st["num_spheres"], W, H, S, B),
+                   "scene_id": args.scene_id, "spheres": st["num_spheres"], "width": W, "height": H, "samples": S, "bounces": B,
+                   "threads": args.threads, "scene_source": args.scene_source, "schedule": args.schedule,
+                   "sharding": ctx["sharding"], "backend": ctx["backend"], "host": ctx["host"]},
+        "kernel_ms_mean": round(kms, 4), "kernel_ms_min": round(float(np.min(ctx["kernel_ms"])), 4),
+        "kernel_ms_mean_max_over_ranks": round(ctx["kernel_mean_max"], 4),
+        "segments_per_ray": round(ctx["segments_total"] / rays, 4),
+        "roofline": roofline_object(args, st, ctx["segments_main0"], ctx["main_ms"], ctx["pmc"], ctx["pmc_note"], world),
+        "step": {"launches": "prepass (%d spp) + cost sort + main" % st["prepass_samples"] if st["phases"] == 2 else "main",
+                 "kernel_ms_mean": round(kms, 4), "prepass_ms": round(float(st["prepass_ms"]), 4),
+                 "scene_prepare_ms": round(float(st["scene_prepare_ms"]), 3),   # host: screening table + grid plan, once per scene, before the first render's start event
+                 "solo_waves": int(st["solo_waves"]),   # > 0: a partly filled GPU (shard, small frame), render_solo_kernel (DESIGN.md 4.3)
+                 "algorithmic_flops": flops_step, "algorithmic_TFLOPs": round(flops_step / (kms * 1e-3) / 1e12, 3),
+                 "algorithmic_frac": round(flops_step / (kms * 1e-3) / 1e12 / peak, 4)},
+    }
+    trip_us = ctx["trip_us"]
+    line["scaling_detail"] = {
+        "floor_ms": round(ctx["floor_ms"], 4), "floor_is": "prepass_ms + longest per-pixel chain of the main launch x the trip latency of a lone ray on an idle GPU (1-pixel probe), max over ranks: "
+                                                            "what a rank reaches if its longest chain runs undisturbed from the first trip; shards run it at 1.6-2x that "
+                                                            "latency, two heavy pixels per solo wave beside the loaded SIMDs (DESIGN.md sections 4.3, 5)",
+        "longest_chain_segments": ctx["chain_max"], "lone_ray_trip_us": round(trip_us, 4) if trip_us else None,
+        "lone_ray_probe": "1x1 frame, 400 spp, %d segments" % ctx["trip_segments"],
+        "kernel_ms_per_rank": ctx["kernel_ms_per_rank"], "gather_ms_per_rank": ctx["gather_ms_per_rank"],
+        "gather_ms": round(ctx["gather_ms"], 4) if ctx["gather_ms"] is not None else None,
+        "gather_transport": ctx.get("gather_transport"),
+        "gather_bytes_total": int(W) * H * 3 * (4 if prec == 32 else 8) if world > 1 or ctx["backend"] else 0}
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args)
+        line["cpu_baseline"]["config1"] = cpu_baseline_config1()
     sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # under torch.distributed.run the job is distributed whatever its size (see the docstring)
-    distributed = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ)
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    os.write(json_fd, (json.dumps(line) + "\n").encode())
+
+
+def run_group(args, json_fd):
+    """N > 1 without a launcher: ONE process, the library's own group over the node's GPUs (include/rtiow.h)."""
+    import raytracingincuda_amd as rt
+    N = args.gpus
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(N))
+    if len(devices) != N:
+        raise SystemExit("--devices lists %d devices for --gpus %d" % (len(devices), N))
+    prec = args.precision
+    W, H, S, B = args.width, args.height, args.samples, args.bounces
+    scene = rt.build_scene(args.scene_id, prec)
+    cam = rt.camera(prec, W, H, S, B)
+    gather = {"auto": rt.GATHER_AUTO, "rccl": rt.GATHER_RCCL, "peer": rt.GATHER_PEER}[args.gather]
+    g = rt.RendererGroup(N, prec, args.strip_rows, gather, devices)      # raises when the node has fewer GPUs or the HIP library is missing
+    g.set_camera(cam)
+    g.set_scene(scene)
+    g.set_scene_source(getattr(rt, SOURCES[args.scene_source]))
+    g.set_schedule(getattr(rt, SCHEDULES[args.schedule]))
+    g.init_rng(1227)                                    # untimed, like main.cu:326-330
+    members = [g.member(k) for k in range(N)]
+    segments = [m.count_segments(args.threads) for m in members]          # untimed; also a first warm launch per device
+    chains = [int(m.stats()["max_chain_main"]) for m in members]
+    segments_main0 = int(members[0].stats()["segments_main"])
+    trip_us, trip_segments = (None, 0) if args.no_scaling_probe else lone_ray_trip_us(rt, devices[0], prec, scene, args)
+
+    for _ in range(args.warmup):
+        g.render(args.threads)
+        g.gather()
+    for m in members:
+        m.synchronize()
+    kernel_ms, main_ms, gather_ms, per_rank = [], [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        kernel_ms.append(g.render(args.threads))         # every device's launches are enqueued, then every stop event awaited: max over devices
+        g.gather()                                       # the one exchange + de-interleave on device 0 (blocks on its stop event)
+        gs = g.stats()
+        per_rank.append(gs["kernel_ms"])
+        gather_ms.append(gs["gather_ms"])
+        main_ms.append(members[0].stats()["main_ms"])
+    for m in members:
+        m.synchronize()
+    elapsed = time.perf_counter() - t0
+    gs = g.stats()
+    sts = [m.stats() for m in members]
+    floor = max(float(sts[k]["prepass_ms"]) + chains[k] * (trip_us or 0.0) * 1e-3 for k in range(N))
+    ctx = {"world": N, "elapsed": elapsed, "kernel_ms": kernel_ms, "main_ms": main_ms, "stats0": sts[0], "segments0": segments[0],
+           "segments_main0": segments_main0, "segments_total": float(sum(segments)), "kernel_mean_max": float(np.mean(kernel_ms)),
+           "kernel_ms_per_rank": [round(float(x), 4) for x in np.mean(np.array(per_rank), axis=0)],
+           "gather_ms_per_rank": None, "gather_ms": float(np.mean(gather_ms)),
+           "gather_transport": {rt.GATHER_RCCL: "rccl %d (ncclSend/ncclRecv to device 0)" % gs["rccl_version"], rt.GATHER_PEER: "peer copies" + (": " + gs["transport_note"] if gs["transport_note"] else "")}.get(gs["gather_mode"], "none"),
+           "floor_ms": floor, "chain_max": max(chains), "trip_us": trip_us, "trip_segments": trip_segments,
+           "sharding": "interleaved %d-row strips over %d ranks, one exchange to rank 0 inside the step" % (args.strip_rows, N),
+           "backend": "rtiow_group (in-library RCCL / peer copies)", "host": "one process, devices %s" % ",".join(str(d) for d in devices),
+           "pmc": None, "pmc_note": "counter passes run at N = 1 only"}
+    emit(json_fd, args, ctx)
+    g.close()
+
+
+def run_ranks(args, json_fd, world, rank, local_rank, distributed, pmc, pmc_note):
+    """N = 1, or one process per GPU under torch.distributed.run."""
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # RTIOW_BENCH_BACKEND=gloo is a REHEARSAL mode for boxes with fewer GPUs than ranks (ranks
     # share devices, the gather bounces through the host); the real multi-GPU run uses RCCL.
     backend = os.environ.get("RTIOW_BENCH_BACKEND", "nccl")
     device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    if not distributed and args.devices:
+        device_index = int(args.devices.split(",")[0])
     torch.cuda.set_device(device_index)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -201,8 +373,6 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    if args.strip_rows <= 0:
-        args.strip_rows = 8 if world <= 2 else 2
     import raytracingincuda_amd as rt
     from raytracingincuda_amd.distributed import StripGather
 
@@ -217,8 +387,8 @@ def main():
     r.set_stream(stream.cuda_stream)
     r.set_camera(cam)
     r.set_scene(scene)
-    r.set_scene_source({"grid": rt.SCENE_GRID, "lds": rt.SCENE_LDS, "scalar": rt.SCENE_SCALAR, "lds_exact": rt.SCENE_LDS_EXACT}[args.scene_source])
-    r.set_schedule({"sorted": rt.SCHED_SORTED, "persistent": rt.SCHED_PERSISTENT, "static": rt.SCHED_STATIC}[args.schedule])
+    r.set_scene_source(getattr(rt, SOURCES[args.scene_source]))
+    r.set_schedule(getattr(rt, SCHEDULES[args.schedule]))
     r.set_shard(rank, world, args.strip_rows)
     gather = StripGather(W, H, rank, world, args.strip_rows, tdtype, "cuda:%d" % device_index, stage_via_cpu=(backend != "nccl"),
                          always_collective=distributed)
@@ -226,10 +396,19 @@ def main():
     r.bind_framebuffer(view.data_ptr(), view.numel() * view.element_size())
     r.init_rng(1227)                                   # untimed, like main.cu:326-330
     segments = r.count_segments(args.threads)          # untimed; also a first warm launch
-    nspheres = r.stats()["num_spheres"]
-
+    segments_main0 = int(r.stats()["segments_main"])
     chain_main = int(r.stats()["max_chain_main"])      # this rank's longest per-pixel chain in the main launch
     trip_us, trip_segments = (None, 0) if args.no_scaling_probe else lone_ray_trip_us(rt, device_index, prec, scene, args)
+
+    if world > 1:
+        pmc, pmc_note = None, "counter passes run at N = 1 only"
+    elif args.pmc == "off":
+        pmc, pmc_note = None, "--pmc off"
+    elif pmc is None and args.pmc in ("auto", "committed"):      # no live passes (asked not to, or they failed): the committed record, if it is of THIS build
+        rec, note = pmc_committed(args, rt.build_id())
+        pmc, pmc_note = rec, (pmc_note + "; " if pmc_note else "") + note
+    if pmc is not None and pmc.get("build_id") != rt.build_id():
+        pmc, pmc_note = None, "counters were taken on build %s..., the loaded library is %s..." % (str(pmc.get("build_id"))[:12], rt.build_id()[:12])
 
     main_ms = []
     gather_events = []
@@ -282,77 +461,50 @@ def main():
         kernel_ms_per_rank, gather_ms_per_rank = [round(float(np.mean(kernel_ms)), 4)], None
 
     if rank == 0:
-        rays = float(W) * H * S
-        ms_per_step = elapsed / args.steps * 1e3
-        value = rays / (ms_per_step * 1e-3) / 1e6
-        # roofline of the dominant kernel (rank 0's launches; for N>1 this rank's shard)
-        st = r.stats()
-        my_rays = float(st["primary_rays"])
-        my_segments = float(segments)
-        per_seg = 23.0 * nspheres + 120.0
-        flops_step = my_segments * per_seg + my_rays * 60.0
-        kms = float(np.mean(kernel_ms))
-        peak = VALU_FP32_PEAK_TFLOPS if prec == 32 else VALU_FP64_PEAK_TFLOPS
-        rays_main = my_rays * (S - st["prepass_samples"]) / S
-        flops = float(st["segments_main"]) * per_seg + rays_main * 60.0       # the main launch alone
-        mms = float(np.mean(main_ms))
-        achieved = flops / (mms * 1e-3) / 1e12
-        # algorithmic HBM bytes of the main launch, per pixel: the framebuffer write (3 T) + its starting state:
-        # the 48/64-byte hand-over record and a 4-byte order entry (sorted schedule) or the 24-byte RNG state
-        my_pixels = my_rays / S
-        state_bytes = ((48 if prec == 32 else 64) + 4) if st["phases"] == 2 else 24
-        fb_bytes = my_pixels * (3 * (4 if prec == 32 else 8) + state_bytes)
-        traffic, fetch_b, write_b = pmc_traffic(args) if world == 1 and args.schedule == "sorted" else (None, None, None)
-        line = {
-            "metric": "Mrays/s (= W x H x samples / render time)",
-            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32" if prec == 32 else "f64", "data": "synthetic",
-            "config": {"workload": "scene %d (%d spheres), %dx%d, %d spp, %d bounces, XORWOW seed 1227" % (args.scene_id, nspheres, W, H, S, B),
-                       "scene_id": args.scene_id, "spheres": nspheres, "width": W, "height": H, "samples": S, "bounces": B,
-                       "threads": args.threads, "scene_source": args.scene_source, "schedule": args.schedule,
-                       "sharding": "interleaved %d-row strips, gather to rank 0 inside the step" % args.strip_rows if distributed else "none",
-                       "backend": backend if distributed else None},
-            "kernel_ms_mean": round(kms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
-            "kernel_ms_mean_max_over_ranks": round(kernel_mean_max, 4),
-            "segments_per_ray": round(segments_total / rays, 4),
-            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic,   # the PMC passes: one GPU, full frame, default schedule
-                         "fetch_bytes": fetch_b, "write_bytes": write_b,   # the same passes, raw FETCH_SIZE / WRITE_SIZE of the main launch (the sorted schedule stores pixels in cost order: writes exceed the 12 B/pixel framebuffer)
-                         "kernel": "%s<%s>" % ("render_kernel" if args.schedule == "static" else "render_persistent_kernel", "float" if prec == 32 else "double"),
-                         "launch_ms_mean": round(mms, 4), "launch_ms_min": round(float(np.min(main_ms)), 4),
-                         "algorithmic_flops_per_launch": flops, "segments_in_launch": int(st["segments_main"]),
-                         "samples_in_launch": int(S - st["prepass_samples"]),
-                         "algorithmic_hbm_bytes_per_launch": fb_bytes,
-                         "hbm_achieved_GBps": round(fb_bytes / (mms * 1e-3) / 1e9, 3), "hbm_peak_GBps": HBM_PEAK_GBS,
-                         "achieved_is": "ALGORITHMIC flops per second: the reference's own sphere loop, 23 flop x every sphere x every segment (SURVEY.md 8d). "
-                                        "The grid walk finds the same hits testing a few spheres per segment, so this figure measures useful work against the "
-                                        "reference's algorithm, not executed arithmetic, and can exceed the peak; 'issued' is what the hardware executed",
-                         "issued": pmc_issue(args) if world == 1 else None},
-            "step": {"launches": "prepass (%d spp) + cost sort + main" % st["prepass_samples"] if st["phases"] == 2 else "main",
-                     "kernel_ms_mean": round(kms, 4), "prepass_ms": round(float(st["prepass_ms"]), 4),
-                     "solo_waves": int(st["solo_waves"]),   # > 0: a partly filled GPU (shard, small frame), render_solo_kernel
-                     "algorithmic_flops": flops_step, "achieved_TFLOPs": round(flops_step / (kms * 1e-3) / 1e12, 3),
-                     "frac_of_peak": round(flops_step / (kms * 1e-3) / 1e12 / peak, 4)},
-        }
-        line["scaling_detail"] = {
-            "floor_ms": round(floor_ms, 4), "floor_is": "prepass_ms + longest per-pixel chain of the main launch x the trip latency of a lone ray on an idle GPU (1-pixel probe), max over ranks: "
-                                                                "what a rank reaches if its longest chain runs undisturbed from the first trip; shards run it at 1.6-2x that "
-                                                                "latency, two heavy pixels per solo wave beside the loaded SIMDs (DESIGN.md sections 4.3, 5)",
-            "longest_chain_segments": chain_max, "lone_ray_trip_us": round(trip_us, 4) if trip_us else None,
-            "lone_ray_probe": "1x1 frame, 400 spp, %d segments" % trip_segments,
-            "kernel_ms_per_rank": kernel_ms_per_rank, "gather_ms_per_rank": gather_ms_per_rank,
-            "gather_ms": round(gather_ms_max, 4) if gather_ms_max is not None else None,
-            "gather_bytes_total": int(W) * H * 3 * (4 if prec == 32 else 8) if distributed else 0}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args)
-            line["cpu_baseline"]["config1"] = cpu_baseline_config1()
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        ctx = {"world": world, "elapsed": elapsed, "kernel_ms": kernel_ms, "main_ms": main_ms, "stats0": r.stats(), "segments0": segments,
+               "segments_main0": segments_main0, "segments_total": segments_total, "kernel_mean_max": kernel_mean_max,
+               "kernel_ms_per_rank": kernel_ms_per_rank, "gather_ms_per_rank": gather_ms_per_rank, "gather_ms": gather_ms_max,
+               "gather_transport": ("torch.distributed gather, backend %s" % backend) if distributed else None,
+               "floor_ms": floor_ms, "chain_max": chain_max, "trip_us": trip_us, "trip_segments": trip_segments,
+               "sharding": "interleaved %d-row strips, gather to rank 0 inside the step" % args.strip_rows if distributed else "none",
+               "backend": backend if distributed else None,
+               "host": "one process per GPU (torch.distributed.run)" if distributed else "one process, device %d" % device_index,
+               "pmc": pmc, "pmc_note": pmc_note}
+        emit(json_fd, args, ctx)
     r.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    # The driver reads ONE JSON line from stdout; libraries are chatty there (RCCL prints a version
+    # banner on stdout when its first communicator is created).  Everything but that line goes to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # under torch.distributed.run the job is distributed whatever its size (see the docstring)
+    distributed = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ)
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.strip_rows <= 0:
+        args.strip_rows = 8 if max(world, args.gpus) <= 2 else 2
+    if args.gpus > 1 and not distributed:
+        return run_group(args, json_fd)                 # no launcher: the in-library group drives the N GPUs from this process
+    # counter passes of THIS run: child processes, started before this process initialises the GPU
+    pmc, pmc_note = None, None
+    if world == 1 and args.pmc in ("auto", "live"):
+        if under_a_profiler():
+            pmc_note = "bench.py itself runs below a profiler: no nested passes"
+        else:
+            pmc, pmc_note = pmc_live(args)
+    run_ranks(args, json_fd, world, rank, local_rank, distributed, pmc, pmc_note)
 
 
 if __name__ == "__main__":

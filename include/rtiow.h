@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RTIOW_ABI_VERSION 3
+#define RTIOW_ABI_VERSION 4
 
 #define RTIOW_E_BADARG   (-1)
 #define RTIOW_E_STATE    (-2)   /* call order violated (e.g. render before set_scene) */
@@ -116,12 +116,21 @@ typedef struct {
     /* RTIOW_SCHED_SORTED on a partly filled GPU (small frame, shard): waves that held only the top-ranked
      * pixels, and how many each (0: the plain kernel ran) */
     int32_t  solo_waves, solo_lanes;
+    /* Host time of the per-scene pre-processing the render kernels rely on -- screening table + uniform-grid plan
+     * and blob (build_screen_table, build_grid_tables) -- spent once per rtiow_set_scene, at the first render after
+     * it, BEFORE the start event of that render: like the reference's scene set-up (main.cu:148-321) it is outside
+     * render_only and inside end_to_end.  0 when the last scene needed no tables (scalar / exact sources). */
+    double   scene_prepare_ms;
 } rtiow_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------
  * rtiow_create replaces cudaSetDevice(0) + event creation (main.cu:81-92).
  * precision is 32 (GlobalFloat) or 64 (GlobalDouble). */
 int rtiow_abi_version(void);
+/* SHA-256 (hex) of the sources and compiler flags this library was built from (raytracingincuda_amd/build.py
+ * passes it in; "unknown" for a hand build).  Profiles record it, and bench.py reports counter-derived figures
+ * only from records taken with the very build that is loaded. */
+const char* rtiow_build_id(void);
 int rtiow_create(int device, int precision, rtiow_handle* out);
 int rtiow_destroy(rtiow_handle h);                                   /* main.cu:384-388 */
 const char* rtiow_last_error_string(rtiow_handle h);                 /* main.cu:14-21   */
@@ -253,15 +262,22 @@ typedef struct {
     double   kernel_ms_max;                     /* = what rtiow_group_render returned */
     double   gather_ms;                         /* HIP events on device 0 around exchange + de-interleave, opened when the last render finished */
     uint64_t gather_bytes;                      /* bytes that arrived on device 0 */
+    double   create_ms;                         /* wall time of rtiow_group_create: contexts, streams and -- RCCL -- ncclCommInitAll
+                                                 * (seconds: topology discovery); like the reference's cudaSetDevice / event creation
+                                                 * (main.cu:81-92) it lies BEFORE the end-to-end timer of the executables */
+    int32_t  peer_links;                        /* peer mode: ranks whose device got direct access to device 0 enabled */
+    int32_t  reserved;
 } rtiow_group_stats;
 
 /* devices == NULL: devices 0..ngpus-1.  A device may be listed more than once (ranks then share
  * it and the exchange uses copies: RCCL needs distinct devices) -- used to test the N-rank logic
  * on a one-GPU box. */
 /* The transport is chosen and the RCCL communicator created here (seconds: keep it out of timed
- * regions); RTIOW_GATHER_RCCL fails here (RTIOW_E_STATE) when RCCL cannot serve the group. */
+ * regions; rtiow_group_stats.create_ms); RTIOW_GATHER_RCCL fails here (RTIOW_E_STATE) when RCCL cannot serve the
+ * group.  RCCL prints a version banner on stdout when a process creates its first communicator: a caller whose
+ * stdout is data (the executables' CSV fragment) points fd 1 elsewhere around this call -- the library does not. */
 int rtiow_group_create(int ngpus, const int* devices, int precision, int strip_rows, int gather, rtiow_group* out);
-const char* rtiow_group_create_error(void);   /* text for the last failed rtiow_group_create of this process */
+const char* rtiow_group_create_error(void);   /* text for the calling thread's last failed rtiow_group_create */
 int rtiow_group_destroy(rtiow_group g);
 const char* rtiow_group_last_error_string(rtiow_group g);
 int rtiow_group_size(rtiow_group g);
@@ -281,6 +297,12 @@ int rtiow_group_read_framebuffer(rtiow_group g, void* host_rgb, size_t bytes);
 int rtiow_group_get_stats(rtiow_group g, rtiow_group_stats* out);
 /* Why RTIOW_GATHER_AUTO fell back to peer copies ("" if it did not). */
 const char* rtiow_group_transport_note(rtiow_group g);
+/* Test hook, host only (no GPU, no RCCL): the exchange's schedule -- the very function rtiow_group_gather runs --
+ * against a recording table instead of HIP / RCCL, for n ranks on `devices` with `rows` local rows each.
+ * mode = RTIOW_GATHER_RCCL | RTIOW_GATHER_PEER.  One record of 8 int64 per call (layout: csrc/rtiow_group.hip);
+ * fail_at >= 0 makes that call fail.  Returns the number of records; *schedule_rc = what the schedule returned. */
+int rtiow_debug_gather_schedule(int n, const int* devices, const int* rows, int W, int precision, int mode, int fail_at,
+                                int64_t* records, size_t cap_records, int* schedule_rc);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,7 @@ SCENE_LDS, SCENE_SCALAR, SCENE_LDS_EXACT, SCENE_GRID = 0, 1, 2, 3
 SCHED_STATIC, SCHED_PERSISTENT, SCHED_SORTED = 0, 1, 2
 GATHER_AUTO, GATHER_RCCL, GATHER_PEER = 0, 1, 2
 GROUP_MAX_STATS = 16
+ABI_VERSION = 4          # include/rtiow.h RTIOW_ABI_VERSION
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIBDIR = os.path.join(_PKG, "lib")
@@ -68,18 +69,19 @@ class Stats(ctypes.Structure):
                 ("max_chain_prepass", ctypes.c_uint64), ("max_chain_main", ctypes.c_uint64),
                 ("grid_nx", ctypes.c_int32), ("grid_nz", ctypes.c_int32), ("grid_registered", ctypes.c_int32),
                 ("grid_direct", ctypes.c_int32), ("grid_cell", ctypes.c_double),
-                ("solo_waves", ctypes.c_int32), ("solo_lanes", ctypes.c_int32)]
+                ("solo_waves", ctypes.c_int32), ("solo_lanes", ctypes.c_int32), ("scene_prepare_ms", ctypes.c_double)]
 
 
 class GroupStats(ctypes.Structure):
     _fields_ = [("ngpus", ctypes.c_int32), ("strip_rows", ctypes.c_int32), ("gather_mode", ctypes.c_int32),
                 ("rccl_version", ctypes.c_int32), ("kernel_ms", ctypes.c_double * GROUP_MAX_STATS),
-                ("kernel_ms_max", ctypes.c_double), ("gather_ms", ctypes.c_double), ("gather_bytes", ctypes.c_uint64)]
+                ("kernel_ms_max", ctypes.c_double), ("gather_ms", ctypes.c_double), ("gather_bytes", ctypes.c_uint64),
+                ("create_ms", ctypes.c_double), ("peer_links", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 # Every symbol include/rtiow.h declares (tests check that the built library exports them all).
 HIP_SYMBOLS = [
-    "rtiow_abi_version", "rtiow_create", "rtiow_destroy", "rtiow_last_error_string", "rtiow_set_stream",
+    "rtiow_abi_version", "rtiow_build_id", "rtiow_create", "rtiow_destroy", "rtiow_last_error_string", "rtiow_set_stream",
     "rtiow_set_scene", "rtiow_set_camera", "rtiow_set_shard", "rtiow_local_rows", "rtiow_local_row_map",
     "rtiow_init_rng", "rtiow_render", "rtiow_count_segments", "rtiow_bind_framebuffer", "rtiow_framebuffer_device_ptr",
     "rtiow_read_framebuffer", "rtiow_set_scene_source", "rtiow_set_schedule", "rtiow_get_stats", "rtiow_synchronize",
@@ -88,7 +90,7 @@ HIP_SYMBOLS = [
     "rtiow_group_create", "rtiow_group_create_error", "rtiow_group_destroy", "rtiow_group_last_error_string", "rtiow_group_size", "rtiow_group_member",
     "rtiow_group_set_scene", "rtiow_group_set_camera", "rtiow_group_set_scene_source", "rtiow_group_set_schedule",
     "rtiow_group_init_rng", "rtiow_group_render", "rtiow_group_gather", "rtiow_group_framebuffer_device_ptr",
-    "rtiow_group_read_framebuffer", "rtiow_group_get_stats", "rtiow_group_transport_note",
+    "rtiow_group_read_framebuffer", "rtiow_group_get_stats", "rtiow_group_transport_note", "rtiow_debug_gather_schedule",
 ]
 HOST_SYMBOLS = [
     "rtiow_host_scene_slots", "rtiow_host_build_scene", "rtiow_host_camera", "rtiow_host_ppm_filename",
@@ -138,6 +140,8 @@ def load_hip_library():
         vp, H = ctypes.c_void_p, ctypes.c_void_p
         i32p = ctypes.POINTER(ctypes.c_int32)
         lib.rtiow_abi_version.argtypes = []
+        lib.rtiow_build_id.argtypes = []
+        lib.rtiow_build_id.restype = ctypes.c_char_p
         lib.rtiow_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(H)]
         lib.rtiow_destroy.argtypes = [H]
         lib.rtiow_last_error_string.argtypes = [H]
@@ -187,8 +191,15 @@ def load_hip_library():
         lib.rtiow_group_framebuffer_device_ptr.argtypes = [G, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
         lib.rtiow_group_read_framebuffer.argtypes = [G, vp, ctypes.c_size_t]
         lib.rtiow_group_get_stats.argtypes = [G, ctypes.POINTER(GroupStats)]
+        lib.rtiow_debug_gather_schedule.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                    ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
         _hip = lib
     return _hip
+
+
+def build_id():
+    """rtiow_build_id() of the loaded HIP library: SHA-256 of the sources + flags it was built from."""
+    return load_hip_library().rtiow_build_id().decode()
 
 
 def _dtype(precision):
@@ -312,6 +323,7 @@ class Renderer:
         self._lib = load_hip_library()
         self.precision = precision
         self.dtype = _dtype(precision)
+        self._borrowed = False
         self._h = ctypes.c_void_p()
         rc = self._lib.rtiow_create(int(device), int(precision), ctypes.byref(self._h))
         if rc:
@@ -319,13 +331,23 @@ class Renderer:
             raise RtiowError(rc, "rtiow_create(device=%d) failed -- is a GPU visible?" % device)
         self.width = self.height = 0
 
+    @classmethod
+    def _borrow(cls, lib, handle, precision, width, height):
+        """A view of a handle somebody else owns (a member of a RendererGroup): close() leaves it alone."""
+        r = cls.__new__(cls)
+        r._lib, r.precision, r.dtype, r._borrowed = lib, precision, _dtype(precision), True
+        r._h = handle
+        r.width, r.height = width, height
+        return r
+
     def _check(self, rc):
         if rc:
             raise RtiowError(rc, self._lib.rtiow_last_error_string(self._h).decode(errors="replace"))
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.rtiow_destroy(self._h)
+            if not self._borrowed:
+                self._lib.rtiow_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -463,6 +485,21 @@ class Renderer:
         return out
 
 
+def debug_gather_schedule(devices, rows, width, precision=32, mode=GATHER_RCCL, fail_at=-1):
+    """The exchange's schedule (rtiow_group_gather's own) run against a recorder: (list of 8-tuples, return code).
+    Host only -- no GPU, no RCCL.  Record layout: csrc/rtiow_group.hip, rtiow_debug_gather_schedule."""
+    lib = load_hip_library()
+    n = len(devices)
+    cap = 16 * n + 16
+    rec = (ctypes.c_int64 * (8 * cap))()
+    rc = ctypes.c_int(0)
+    got = lib.rtiow_debug_gather_schedule(n, (ctypes.c_int * n)(*devices), (ctypes.c_int * n)(*rows), int(width), int(precision), int(mode), int(fail_at),
+                                          rec, cap, ctypes.byref(rc))
+    if got < 0:
+        raise RtiowError(got, "rtiow_debug_gather_schedule: bad arguments")
+    return [tuple(rec[8 * k: 8 * k + 8]) for k in range(got)], rc.value
+
+
 class RendererGroup:
     """Several GPUs of one node driven from this process (rtiow_group_*, include/rtiow.h): interleaved
     row strips, one exchange to device 0 after the render (RCCL, or peer copies), de-interleaved there.
@@ -538,6 +575,12 @@ class RendererGroup:
 
     def gather(self):
         self._check(self._lib.rtiow_group_gather(self._g))
+
+    def member(self, rank):
+        """Rank `rank`'s own handle as a borrowed Renderer (per-device stats, count_segments, knobs)."""
+        h = ctypes.c_void_p()
+        self._check(self._lib.rtiow_group_member(self._g, int(rank), ctypes.byref(h)))
+        return Renderer._borrow(self._lib, h, self.precision, self.width, self.height)
 
     def read_framebuffer(self):
         """Exchange + de-interleave on device 0, then the full [H, W, 3] image."""

@@ -52,6 +52,22 @@ def hip_includes():
     return out
 
 
+def hip_build_id(extra_flags=()):
+    """SHA-256 over the HIP library's sources (in a fixed order), its public header and the compiler flags:
+    what `rtiow_build_id()` of the built library returns.  PMC records under profiles/ carry the id of the build
+    they were measured on; bench.py uses a record only when it matches the library that is loaded."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, "rtiow_hip.hip"), os.path.join(CSRC, "rtiow_group.hip")] + hip_includes() + [os.path.join(INC, "rtiow.h")]
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode() + b"\0")
+        h.update(open(f, "rb").read())
+        h.update(b"\0")
+    flags = [f for f in HIP_FLAGS if not f.startswith("-I")] + list(extra_flags)
+    h.update(" ".join(flags).encode())
+    return h.hexdigest()
+
+
 def _run(cmd, verbose):
     if verbose:
         print("+", " ".join(cmd), flush=True)
@@ -63,7 +79,7 @@ def build_stats(verbose=True):
     (lib/librtiow_hip_stats.so, -DRTIOW_PATH_STATS; used by scripts/path_stats_probe.py only)."""
     os.makedirs(LIB, exist_ok=True)
     out = os.path.join(LIB, "librtiow_hip_stats.so")
-    _run([_hipcc()] + HIP_FLAGS + ["-DRTIOW_PATH_STATS", "-o", out, os.path.join(CSRC, "rtiow_hip.hip"), os.path.join(CSRC, "rtiow_group.hip"), "-ldl"], verbose)
+    _run([_hipcc()] + HIP_FLAGS + ["-DRTIOW_PATH_STATS", '-DRTIOW_BUILD_ID="%s"' % hip_build_id(["-DRTIOW_PATH_STATS"]), "-o", out, os.path.join(CSRC, "rtiow_hip.hip"), os.path.join(CSRC, "rtiow_group.hip"), "-ldl"], verbose)
     return out
 
 
@@ -77,7 +93,7 @@ def build(force=False, verbose=True):
     hip_so = os.path.join(LIB, "librtiow_hip.so")
     if force or _newer(hip_so, hip_srcs + hip_includes() + [me] + headers):
         # librccl is NOT linked: rtiow_group.hip dlopens it on first use (-ldl for old glibc)
-        _run([_hipcc()] + HIP_FLAGS + ["-o", hip_so] + hip_srcs + ["-ldl"], verbose)
+        _run([_hipcc()] + HIP_FLAGS + ['-DRTIOW_BUILD_ID="%s"' % hip_build_id(), "-o", hip_so] + hip_srcs + ["-ldl"], verbose)
 
     host_src = os.path.join(CSRC, "host", "rtiow_host.cpp")
     host_so = os.path.join(LIB, "librtiow_host.so")

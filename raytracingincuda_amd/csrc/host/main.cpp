@@ -7,6 +7,8 @@
 // end_to_end_ms), output file name and P3 format, so the reference's *_benchmark.sh,
 // process.py and ppm_diff tooling work unchanged.  The phases below are in the order of
 // main.cu:37-400; each device phase is one call into the C-ABI (include/rtiow.h).
+#include <unistd.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -152,6 +154,21 @@ void check_group(rtiow_group g, int rc) {
     std::exit(rc);
 }
 
+// stdout is the reference's CSV fragment (main.cu:342-343, 397-398) and RCCL prints a version banner there when the
+// process creates its first communicator: while the group is created, file descriptor 1 points at stderr.  This
+// program owns its stdout and is single-threaded, so the redirection is safe here (it is not inside the library).
+struct StdoutToStderr {
+    int saved = -1;
+    StdoutToStderr() { std::fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
+    ~StdoutToStderr() { std::fflush(stdout); if (saved >= 0) { dup2(saved, 1); close(saved); } }
+};
+
+// Releases the group (communicators, streams, device buffers) on every way out of main_multi_gpu.
+struct GroupGuard {
+    rtiow_group g = nullptr;
+    ~GroupGuard() { if (g) (void)rtiow_group_destroy(g); }
+};
+
 // --gpus N: the same phases as main() below, each through the group twin of the call.
 int main_multi_gpu(const Options& opt) {
     const int precision = RTIOW_PRECISION;
@@ -163,8 +180,14 @@ int main_multi_gpu(const Options& opt) {
     }
     const int strip_rows = opt.strip_rows > 0 ? opt.strip_rows : (n <= 2 ? 8 : 2);
     rtiow_group g = nullptr;
-    int rc = rtiow_group_create(n, opt.devices.empty() ? nullptr : opt.devices.data(), precision, strip_rows, opt.gather, &g);   // main.cu:81-92, per device
+    int rc;
+    // Device contexts, streams and the RCCL communicator (ncclCommInitAll: seconds) are created before the end-to-end
+    // timer starts, where the reference has cudaSetDevice + event creation (main.cu:81-92 vs :95); --stats reports
+    // the time as wall_ms.group_create, and end_to_end does NOT contain it.
+    { StdoutToStderr quiet; rc = rtiow_group_create(n, opt.devices.empty() ? nullptr : opt.devices.data(), precision, strip_rows, opt.gather, &g); }   // main.cu:81-92, per device
     if (rc) { std::fprintf(stderr, "HIP_SAFE_CALL: cannot open %d device(s) (error %d) %s\n", n, rc, rtiow_group_create_error()); return rc; }
+    GroupGuard guard;
+    guard.g = g;
     const auto e2e_start = std::chrono::steady_clock::now();                 // main.cu:95
     auto lap = [last = e2e_start]() mutable {
         const auto now = std::chrono::steady_clock::now();
@@ -210,6 +233,7 @@ int main_multi_gpu(const Options& opt) {
     std::memset(&gs, 0, sizeof gs);
     rtiow_group_get_stats(g, &gs);
     const std::string note = rtiow_group_transport_note(g);
+    guard.g = nullptr;
     check_group(g, rtiow_group_destroy(g));
     const double e2e_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - e2e_start).count();
     std::printf("%15.8f\n", e2e_ms);
@@ -220,10 +244,12 @@ int main_multi_gpu(const Options& opt) {
         std::fprintf(stderr,
                      "{\"mrays_per_s\": %.3f, \"render_ms\": %.6f, \"gpus\": %d, \"strip_rows\": %d, \"kernel_ms\": [%s], "
                      "\"gather\": \"%s\", \"rccl_version\": %d, \"gather_ms\": %.6f, \"gather_bytes\": %llu, \"transport_note\": \"%s\", "
-                     "\"wall_ms\": {\"setup\": %.3f, \"rng_init\": %.3f, \"render\": %.3f, \"gather_and_readback\": %.3f, \"ppm_write\": %.3f, \"end_to_end\": %.3f}}\n",
+                     "\"peer_links\": %d, "
+                     "\"wall_ms\": {\"group_create\": %.3f, \"setup\": %.3f, \"rng_init\": %.3f, \"render\": %.3f, \"gather_and_readback\": %.3f, \"ppm_write\": %.3f, \"end_to_end\": %.3f}, "
+                     "\"end_to_end_excludes\": \"group_create\"}\n",
                      render_ms > 0 ? rays / render_ms / 1e3 : 0.0, (double)render_ms, n, strip_rows, per.c_str(),
                      gs.gather_mode == RTIOW_GATHER_RCCL ? "rccl" : "peer", gs.rccl_version, gs.gather_ms, (unsigned long long)gs.gather_bytes, note.c_str(),
-                     t_setup, t_rng, t_render, t_read, t_write, e2e_ms);
+                     gs.peer_links, gs.create_ms, t_setup, t_rng, t_render, t_read, t_write, e2e_ms);
     }
     return 0;
 }
@@ -311,10 +337,10 @@ int main(int argc, char** argv) {
         const double rays = (double)opt.width * opt.height * opt.samples;
         std::fprintf(stderr,
                      "{\"mrays_per_s\": %.3f, \"render_ms\": %.6f, \"rng_init_ms\": %.6f, \"spheres\": %d, \"block\": [%d, %d], "
-                     "\"vgprs\": %d, \"lds_bytes\": %d, \"scene_source\": \"%s\", \"solo_waves\": %d, "
+                     "\"vgprs\": %d, \"lds_bytes\": %d, \"scene_source\": \"%s\", \"solo_waves\": %d, \"scene_prepare_ms\": %.3f, "
                      "\"wall_ms\": {\"setup\": %.3f, \"rng_init\": %.3f, \"render\": %.3f, \"readback\": %.3f, \"ppm_write\": %.3f, \"destroy\": %.3f, \"end_to_end\": %.3f}}\n",
                      render_ms > 0 ? rays / render_ms / 1e3 : 0.0, (double)render_ms, st.rng_init_ms, st.num_spheres,
-                     st.block_x, st.block_y, st.vgprs, st.lds_bytes, st.scene_source == RTIOW_SCENE_GRID ? "grid" : (st.scene_source == RTIOW_SCENE_SCALAR ? "scalar" : "lds"), st.solo_waves,
+                     st.block_x, st.block_y, st.vgprs, st.lds_bytes, st.scene_source == RTIOW_SCENE_GRID ? "grid" : (st.scene_source == RTIOW_SCENE_SCALAR ? "scalar" : "lds"), st.solo_waves, st.scene_prepare_ms,
                      t_setup, t_rng, t_render, t_read, t_write, t_destroy, e2e_ms);
     }
     return 0;

@@ -64,9 +64,11 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         effective_source = RTIOW_SCENE_SCALAR;
     }
     if (lds_source && screened && h->screen_dirty) {
+        const auto t0 = std::chrono::steady_clock::now();
         int rc = build_screen_table<T>(h);
         if (rc) return rc;
         if ((rc = build_grid_tables<T>(h))) return rc;
+        h->stats.scene_prepare_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     fill_screen_params<T>(p, h);
     if (!lds_source) p.use_screen = 0;

@@ -46,6 +46,7 @@ int upload_scene(rtiow_handle_s* h, int n, const T* cr, const T* af, const T* ri
     HIP_TRY(h, hipMemcpy(h->shade_tbl, st.data(), sizeof(T) * 12 * m, hipMemcpyHostToDevice));
     h->n = m; h->n_padded = mp;
     h->stats.num_spheres = m;
+    h->stats.scene_prepare_ms = 0;
     return 0;
 }
 

@@ -27,9 +27,9 @@
 #include <rccl/rccl.h>   // types and prototypes only; every call goes through dlsym'ed pointers
 
 #include <dlfcn.h>
-#include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -88,6 +88,108 @@ struct RcclApi {
     }
 };
 
+// ---- the exchange as a schedule over a table of calls --------------------------------------------------------
+// Everything rtiow_group_gather asks of HIP and RCCL between its two timing events goes through this table, so
+// that the schedule itself -- which call, on which device / stream / communicator, with which counts and offsets,
+// in which order, and which events fence it -- can run against a recorder on a machine without GPUs
+// (rtiow_debug_gather_schedule, tests/test_group_schedule.py).  The real table (hip_backend) forwards to
+// hip* / nccl*; every entry returns 0 or the failing call's error code.
+struct GatherBackend {
+    void* self;
+    int (*set_device)(void* self, int dev);
+    int (*stream_wait_event)(void* self, hipStream_t s, hipEvent_t e);
+    int (*event_record)(void* self, hipEvent_t e, hipStream_t s);
+    int (*copy_async)(void* self, void* dst, const void* src, size_t bytes, hipStream_t s);                                   // same device
+    int (*copy_peer_async)(void* self, void* dst, int dst_dev, const void* src, int src_dev, size_t bytes, hipStream_t s);  // across devices
+    int (*group_start)(void* self);
+    int (*group_end)(void* self);
+    int (*send)(void* self, const void* buf, size_t count, int fp64, int peer, void* comm, hipStream_t s);
+    int (*recv)(void* self, void* buf, size_t count, int fp64, int peer, void* comm, hipStream_t s);
+};
+
+struct GatherInputs {
+    int n, mode, W, fp64;                        // ranks, RTIOW_GATHER_RCCL | _PEER, image width, element type
+    const int* dev;                              // device of every rank
+    const int* rows;                             // local rows of every rank
+    const unsigned long long* offsets;           // element offset of every rank's block in the staging buffer (rank-major)
+    void* const* fb;                             // every rank's strip framebuffer (on its device)
+    void* staged;                                // device 0: rank-major staging buffer
+    const hipStream_t* stream;                   // every rank's stream; stream[0] carries the exchange on device 0
+    const hipEvent_t* done;                      // per rank: its render (and, peer mode, afterwards its copy) is complete
+    hipEvent_t g0;                               // device 0: start of the timed exchange
+    void* const* comms;                          // RCCL mode: every rank's communicator
+};
+
+// Rank k's strips -> staged + offsets[k], for every k, fenced so that (i) nothing starts before the LAST render has
+// finished and device 0 has recorded g0 (the timed region then holds the exchange alone), and (ii) stream[0] has
+// every block when this returns its last call (the caller launches the de-interleave on stream[0] next).
+// Ranks without rows take no part on either side.  `where` names the failing call.
+int run_gather_schedule(const GatherInputs& in, const GatherBackend& be, const char*& where) {
+#define GB(call, name) do { const int rc_ = (call); if (rc_) { where = name; return rc_; } } while (0)
+    const size_t es = in.fp64 ? 8 : 4;
+    hipStream_t s0 = in.stream[0];
+    GB(be.set_device(be.self, in.dev[0]), "hipSetDevice");
+    for (int k = 1; k < in.n; ++k) GB(be.stream_wait_event(be.self, s0, in.done[k]), "hipStreamWaitEvent");
+    GB(be.event_record(be.self, in.g0, s0), "hipEventRecord");
+    if (in.mode == RTIOW_GATHER_RCCL) {
+        for (int k = 1; k < in.n; ++k) {          // a rank's send must not start before device 0 opened the timed region
+            GB(be.set_device(be.self, in.dev[k]), "hipSetDevice");
+            GB(be.stream_wait_event(be.self, in.stream[k], in.g0), "hipStreamWaitEvent");
+        }
+        int r = be.group_start(be.self);
+        const char* failed = "ncclGroupStart";
+        for (int k = 0; k < in.n && r == 0; ++k) {
+            const size_t count = (size_t)in.rows[k] * in.W * 3;
+            if (count == 0) continue;
+            failed = "ncclSend";
+            r = be.send(be.self, in.fb[k], count, in.fp64, 0, in.comms[k], in.stream[k]);
+            if (r == 0) { failed = "ncclRecv"; r = be.recv(be.self, (char*)in.staged + in.offsets[k] * es, count, in.fp64, k, in.comms[0], s0); }
+        }
+        const int r2 = be.group_end(be.self);      // always closed, also after a failing call inside the group
+        if (r == 0 && r2 != 0) { r = r2; failed = "ncclGroupEnd"; }
+        if (r != 0) { where = failed; return r; }
+    } else {
+        for (int k = 0; k < in.n; ++k) {
+            const size_t bytes = (size_t)in.rows[k] * in.W * 3 * es;
+            if (bytes == 0) continue;
+            void* dst = (char*)in.staged + in.offsets[k] * es;
+            if (k == 0 || in.dev[k] == in.dev[0]) {
+                GB(be.set_device(be.self, in.dev[0]), "hipSetDevice");
+                GB(be.copy_async(be.self, dst, in.fb[k], bytes, s0), "hipMemcpyAsync");   // s0 already waits for rank k's render
+            } else {
+                GB(be.set_device(be.self, in.dev[k]), "hipSetDevice");
+                GB(be.stream_wait_event(be.self, in.stream[k], in.g0), "hipStreamWaitEvent");
+                GB(be.copy_peer_async(be.self, dst, in.dev[0], in.fb[k], in.dev[k], bytes, in.stream[k]), "hipMemcpyPeerAsync");
+                GB(be.event_record(be.self, in.done[k], in.stream[k]), "hipEventRecord");
+                GB(be.set_device(be.self, in.dev[0]), "hipSetDevice");
+                GB(be.stream_wait_event(be.self, s0, in.done[k]), "hipStreamWaitEvent");
+            }
+        }
+    }
+    GB(be.set_device(be.self, in.dev[0]), "hipSetDevice");
+#undef GB
+    return 0;
+}
+
+// The real table.  self = the group's RcclApi (null entries are never reached in peer mode).
+struct HipBackendSelf { RcclApi* rccl; int last_nccl; };
+GatherBackend hip_backend(HipBackendSelf* self) {
+    GatherBackend b;
+    b.self = self;
+    b.set_device = [](void*, int dev) { return (int)hipSetDevice(dev); };
+    b.stream_wait_event = [](void*, hipStream_t s, hipEvent_t e) { return (int)hipStreamWaitEvent(s, e, 0); };
+    b.event_record = [](void*, hipEvent_t e, hipStream_t s) { return (int)hipEventRecord(e, s); };
+    b.copy_async = [](void*, void* dst, const void* src, size_t bytes, hipStream_t s) { return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s); };
+    b.copy_peer_async = [](void*, void* dst, int dd, const void* src, int sd, size_t bytes, hipStream_t s) { return (int)hipMemcpyPeerAsync(dst, dd, src, sd, bytes, s); };
+    b.group_start = [](void* p) { auto* h = (HipBackendSelf*)p; return h->last_nccl = (int)h->rccl->GroupStart(); };
+    b.group_end = [](void* p) { auto* h = (HipBackendSelf*)p; const int r = (int)h->rccl->GroupEnd(); if (r) h->last_nccl = r; return r; };
+    b.send = [](void* p, const void* buf, size_t count, int fp64, int peer, void* comm, hipStream_t s) {
+        auto* h = (HipBackendSelf*)p; return h->last_nccl = (int)h->rccl->Send(buf, count, fp64 ? ncclDouble : ncclFloat, peer, (ncclComm_t)comm, s); };
+    b.recv = [](void* p, void* buf, size_t count, int fp64, int peer, void* comm, hipStream_t s) {
+        auto* h = (HipBackendSelf*)p; return h->last_nccl = (int)h->rccl->Recv(buf, count, fp64 ? ncclDouble : ncclFloat, peer, (ncclComm_t)comm, s); };
+    return b;
+}
+
 }  // namespace
 
 struct rtiow_group_s {
@@ -105,6 +207,8 @@ struct rtiow_group_s {
     std::vector<ncclComm_t> comms;
     int rccl_version = 0;
     std::string transport_note;                 // why auto mode fell back, if it did
+    int peer_links = 0;                         // peer mode: ranks whose device has direct access to device 0 enabled
+    double create_ms = 0;                       // wall time of rtiow_group_create (contexts, streams, communicator)
     // device 0 buffers
     void* staged = nullptr; size_t staged_bytes = 0;
     void* full = nullptr; size_t full_bytes = 0;
@@ -134,14 +238,11 @@ int gfail_member(rtiow_group_s* g, int k, int rc) {
 #define G_HIP(g, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return gfail_hip((g), e_, __FILE__, __LINE__); } while (0)
 #define G_EACH(g, call) do { for (int k_ = 0; k_ < (g)->n; ++k_) { rtiow_handle hk = (g)->h[(size_t)k_]; int rc_ = (call); if (rc_) return gfail_member((g), k_, rc_); } } while (0)
 
-// RCCL prints a version banner on STDOUT when its first communicator is created ("RCCL version :
-// ... Librccl path : ..."), and stdout is the reference's CSV fragment (main.cu:342-343, 397-398):
-// while RCCL initialises, file descriptor 1 points at stderr.
-struct StdoutToStderr {
-    int saved = -1;
-    StdoutToStderr() { std::fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
-    ~StdoutToStderr() { std::fflush(stdout); if (saved >= 0) { dup2(saved, 1); close(saved); } }
-};
+// NOTE for callers that own stdout: RCCL prints a version banner on STDOUT when a process creates its first
+// communicator ("RCCL version : ... Librccl path : ...").  The library does not touch file descriptors (a dup2 on
+// the process-wide fd 1 from inside a library call races with every other thread that writes there): the drop-in
+// executables point fd 1 at stderr around rtiow_group_create themselves (csrc/host/main.cpp), bench.py does the
+// same for its whole run.
 
 bool distinct_devices(const rtiow_group_s* g) {
     std::vector<int> d = g->dev;
@@ -149,10 +250,25 @@ bool distinct_devices(const rtiow_group_s* g) {
     return std::adjacent_find(d.begin(), d.end()) == d.end();
 }
 
+// Peer mode, however it was chosen: direct xGMI copies where the devices can reach each other (else the runtime
+// stages hipMemcpyPeerAsync through the host).  The copy runs on the SOURCE device's stream, so the source enables
+// access to device 0.  "Already enabled" is success.
+void enable_peer_access_to_root(rtiow_group_s* g) {
+    for (int k = 1; k < g->n; ++k) {
+        const int dk = g->dev[(size_t)k], d0 = g->dev[0];
+        int can = 0;
+        if (dk == d0 || hipDeviceCanAccessPeer(&can, dk, d0) != hipSuccess || !can) { (void)hipGetLastError(); continue; }
+        if (hipSetDevice(dk) != hipSuccess) { (void)hipGetLastError(); continue; }
+        const hipError_t e = hipDeviceEnablePeerAccess(d0, 0);
+        if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) ++g->peer_links;
+        (void)hipGetLastError();
+    }
+}
+
 // Decide the transport once.  AUTO prefers RCCL and records why it did not get it.
 int resolve_transport(rtiow_group_s* g) {
     if (g->gather_mode) return 0;
-    if (g->gather_requested == RTIOW_GATHER_PEER) { g->gather_mode = RTIOW_GATHER_PEER; return 0; }
+    if (g->gather_requested == RTIOW_GATHER_PEER) { g->gather_mode = RTIOW_GATHER_PEER; enable_peer_access_to_root(g); return 0; }
     std::string why;
     bool ok = true;
     if (!distinct_devices(g)) { ok = false; why = "the group maps several ranks to one device (ncclCommInitAll needs distinct devices)"; }
@@ -160,7 +276,7 @@ int resolve_transport(rtiow_group_s* g) {
     if (ok) {
         g->comms.assign((size_t)g->n, nullptr);
         ncclResult_t r;
-        { StdoutToStderr quiet; r = g->rccl.CommInitAll(g->comms.data(), g->n, g->dev.data()); }
+        r = g->rccl.CommInitAll(g->comms.data(), g->n, g->dev.data());
         if (r != ncclSuccess) {
             ok = false;
             why = std::string("ncclCommInitAll: ") + g->rccl.GetErrorString(r);
@@ -174,14 +290,7 @@ int resolve_transport(rtiow_group_s* g) {
     if (g->gather_requested == RTIOW_GATHER_RCCL) return gfail(g, RTIOW_E_STATE, "RCCL gather requested but unavailable: " + why);
     g->transport_note = why;
     g->gather_mode = RTIOW_GATHER_PEER;
-    for (int k = 1; k < g->n; ++k) {            // direct xGMI copies where the devices can reach each other (else the runtime stages them)
-        int can = 0;
-        if (g->dev[(size_t)k] != g->dev[0] && hipDeviceCanAccessPeer(&can, g->dev[(size_t)k], g->dev[0]) == hipSuccess && can) {
-            (void)hipSetDevice(g->dev[(size_t)k]);
-            (void)hipDeviceEnablePeerAccess(g->dev[0], 0);
-            (void)hipGetLastError();
-        }
-    }
+    enable_peer_access_to_root(g);
     return 0;
 }
 
@@ -218,7 +327,7 @@ int ensure_group_buffers(rtiow_group_s* g) {
 
 }  // namespace
 
-namespace { std::string g_create_error; }   // why the last rtiow_group_create of this process failed
+namespace { thread_local std::string g_create_error; }   // why the calling thread's last rtiow_group_create failed
 
 extern "C" {
 
@@ -231,6 +340,7 @@ int rtiow_group_create(int ngpus, const int* devices, int precision, int strip_r
         (gather != RTIOW_GATHER_AUTO && gather != RTIOW_GATHER_RCCL && gather != RTIOW_GATHER_PEER)) return RTIOW_E_BADARG;
     rtiow_group_s* g = new (std::nothrow) rtiow_group_s();
     if (!g) return RTIOW_E_NOMEM;
+    const auto t_create = std::chrono::steady_clock::now();
     g->n = ngpus; g->precision = precision; g->strip_rows = strip_rows; g->gather_requested = gather;
     for (int k = 0; k < ngpus; ++k) g->dev.push_back(devices ? devices[k] : k);
     int rc = 0;
@@ -265,6 +375,8 @@ int rtiow_group_create(int ngpus, const int* devices, int precision, int strip_r
     g_create_error.clear();
     g->stats.ngpus = ngpus; g->stats.strip_rows = strip_rows;
     g->stats.gather_mode = g->gather_mode; g->stats.rccl_version = g->rccl_version;
+    g->stats.create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count();
+    g->stats.peer_links = g->peer_links;
     *out = g;
     return 0;
 }
@@ -372,43 +484,19 @@ int rtiow_group_gather(rtiow_group g) {
         if (bytes != (size_t)g->rows[(size_t)k] * g->W * 3 * es) return gfail(g, RTIOW_E_STATE, "member framebuffer size mismatch");
     }
     hipStream_t s0 = g->stream[0];
-    G_HIP(g, hipSetDevice(g->dev[0]));
-    // the timed region starts when the LAST render has finished, so that it holds the exchange alone
-    for (int k = 1; k < g->n; ++k) G_HIP(g, hipStreamWaitEvent(s0, g->done[(size_t)k], 0));
-    G_HIP(g, hipEventRecord(g->g0, s0));
-    if (g->gather_mode == RTIOW_GATHER_RCCL) {
-        const ncclDataType_t dt = g->precision == 64 ? ncclDouble : ncclFloat;
-        for (int k = 1; k < g->n; ++k) {          // a rank's send must not start before device 0 opened the timed region
-            G_HIP(g, hipSetDevice(g->dev[(size_t)k]));
-            G_HIP(g, hipStreamWaitEvent(g->stream[(size_t)k], g->g0, 0));
-        }
-        ncclResult_t r = g->rccl.GroupStart();
-        for (int k = 0; k < g->n && r == ncclSuccess; ++k) {
-            const size_t count = (size_t)g->rows[(size_t)k] * g->W * 3;
-            if (count == 0) continue;
-            r = g->rccl.Send(fb[(size_t)k], count, dt, 0, g->comms[(size_t)k], g->stream[(size_t)k]);
-            if (r == ncclSuccess)
-                r = g->rccl.Recv((char*)g->staged + g->host_offsets[(size_t)k] * es, count, dt, k, g->comms[0], s0);
-        }
-        const ncclResult_t r2 = g->rccl.GroupEnd();
-        if (r == ncclSuccess) r = r2;
-        if (r != ncclSuccess) return gfail(g, RTIOW_E_STATE, std::string("RCCL gather failed: ") + g->rccl.GetErrorString(r));
-    } else {
-        for (int k = 0; k < g->n; ++k) {
-            const size_t bytes = (size_t)g->rows[(size_t)k] * g->W * 3 * es;
-            if (bytes == 0) continue;
-            void* dst = (char*)g->staged + g->host_offsets[(size_t)k] * es;
-            if (k == 0 || g->dev[(size_t)k] == g->dev[0]) {
-                G_HIP(g, hipSetDevice(g->dev[0]));
-                G_HIP(g, hipMemcpyAsync(dst, fb[(size_t)k], bytes, hipMemcpyDeviceToDevice, s0));   // s0 already waits for rank k's render
-            } else {
-                G_HIP(g, hipSetDevice(g->dev[(size_t)k]));
-                G_HIP(g, hipStreamWaitEvent(g->stream[(size_t)k], g->g0, 0));
-                G_HIP(g, hipMemcpyPeerAsync(dst, g->dev[0], fb[(size_t)k], g->dev[(size_t)k], bytes, g->stream[(size_t)k]));
-                G_HIP(g, hipEventRecord(g->done[(size_t)k], g->stream[(size_t)k]));
-                G_HIP(g, hipSetDevice(g->dev[0]));
-                G_HIP(g, hipStreamWaitEvent(s0, g->done[(size_t)k], 0));
-            }
+    {
+        std::vector<void*> comms((size_t)g->n, nullptr);
+        for (size_t k = 0; k < g->comms.size() && k < comms.size(); ++k) comms[k] = (void*)g->comms[k];
+        GatherInputs in;
+        in.n = g->n; in.mode = g->gather_mode; in.W = g->W; in.fp64 = g->precision == 64;
+        in.dev = g->dev.data(); in.rows = g->rows.data(); in.offsets = g->host_offsets.data(); in.fb = fb.data(); in.staged = g->staged;
+        in.stream = g->stream.data(); in.done = g->done.data(); in.g0 = g->g0; in.comms = comms.data();
+        HipBackendSelf self{&g->rccl, 0};
+        const char* where = "";
+        const int src = run_gather_schedule(in, hip_backend(&self), where);
+        if (src) {
+            if (where[0] == 'n') return gfail(g, RTIOW_E_STATE, std::string("RCCL gather failed in ") + where + ": " + g->rccl.GetErrorString((ncclResult_t)src));
+            return gfail(g, src, std::string("HIP_SAFE_CALL: ") + hipGetErrorString((hipError_t)src) + " in the exchange (" + where + ")");
         }
     }
     G_HIP(g, hipSetDevice(g->dev[0]));
@@ -457,5 +545,70 @@ int rtiow_group_get_stats(rtiow_group g, rtiow_group_stats* out) {
 }
 
 const char* rtiow_group_transport_note(rtiow_group g) { return g ? g->transport_note.c_str() : ""; }
+
+// ---- test hook: the exchange's schedule against a recorder (no GPU, no RCCL) ---------------------------------
+// Runs run_gather_schedule -- the function rtiow_group_gather runs -- with made-up handles and a table that only
+// writes down what it is asked: one record of 8 int64 per call, {op, device in effect, a, b, c, d, e, f}:
+//   op 1 set_device        a = device
+//   op 2 stream_wait_event a = stream id, b = event id
+//   op 3 event_record      a = event id, b = stream id
+//   op 4 copy_async        a = dst byte offset in the staging buffer, b = source rank, c = bytes, d = stream id
+//   op 5 copy_peer_async   a = dst byte offset, b = source rank, c = bytes, d = stream id, e = dst device, f = src device
+//   op 6 group_start       op 7 group_end
+//   op 8 send              a = source rank (by its framebuffer), b = count (elements), c = fp64, d = peer, e = communicator id, f = stream id
+//   op 9 recv              a = dst byte offset, b = count, c = fp64, d = peer, e = communicator id, f = stream id
+// ids: stream of rank k = 1 + k; event done[k] = 100 + k, g0 = 99; communicator of rank k = 200 + k.
+// fail_at >= 0 makes the (fail_at)-th call return an error (the schedule must stop, or -- inside an RCCL group --
+// still close the group).  Returns the number of records, or a negative RTIOW_E_* code.
+int rtiow_debug_gather_schedule(int n, const int* devices, const int* rows, int W, int precision, int mode, int fail_at,
+                                int64_t* records, size_t cap_records, int* schedule_rc) {
+    if (n < 1 || n > 64 || !devices || !rows || W < 1 || (precision != 32 && precision != 64) || !records || !schedule_rc ||
+        (mode != RTIOW_GATHER_RCCL && mode != RTIOW_GATHER_PEER)) return RTIOW_E_BADARG;
+    struct Rec { std::vector<int64_t> v; int device = -1; int calls = 0, fail_at = -1; char* staged; std::vector<void*> fb;
+                 int hit() { return calls++ == fail_at ? 999 : 0; }
+                 int64_t rank_of(const void* p) const { for (size_t k = 0; k < fb.size(); ++k) if (fb[k] == p) return (int64_t)k; return -1; }
+                 void put(int64_t op, int64_t a = 0, int64_t b = 0, int64_t c = 0, int64_t d = 0, int64_t e = 0, int64_t f = 0) {
+                     const int64_t r[8] = {op, device, a, b, c, d, e, f}; v.insert(v.end(), r, r + 8); } } rec;
+    rec.fail_at = fail_at;
+    rec.staged = (char*)(uintptr_t)0x10000000;
+    const size_t es = precision == 64 ? 8 : 4;
+    std::vector<unsigned long long> offsets((size_t)n, 0);
+    std::vector<hipStream_t> stream((size_t)n);
+    std::vector<hipEvent_t> done((size_t)n);
+    std::vector<void*> comms((size_t)n);
+    unsigned long long off = 0;
+    for (int k = 0; k < n; ++k) {
+        offsets[(size_t)k] = off; off += (unsigned long long)rows[k] * W * 3;
+        rec.fb.push_back((void*)(uintptr_t)(0x1000 * (k + 1)));
+        stream[(size_t)k] = (hipStream_t)(uintptr_t)(1 + k); done[(size_t)k] = (hipEvent_t)(uintptr_t)(100 + k); comms[(size_t)k] = (void*)(uintptr_t)(200 + k);
+    }
+    auto id = [](const void* p) { return (int64_t)(uintptr_t)p; };
+    GatherBackend b;
+    b.self = &rec;
+    b.set_device = [](void* p, int dev) { auto* r = (Rec*)p; r->put(1, dev); r->device = dev; return r->hit(); };
+    b.stream_wait_event = [](void* p, hipStream_t s, hipEvent_t e) { auto* r = (Rec*)p; r->put(2, (int64_t)(uintptr_t)s, (int64_t)(uintptr_t)e); return r->hit(); };
+    b.event_record = [](void* p, hipEvent_t e, hipStream_t s) { auto* r = (Rec*)p; r->put(3, (int64_t)(uintptr_t)e, (int64_t)(uintptr_t)s); return r->hit(); };
+    b.copy_async = [](void* p, void* dst, const void* src, size_t bytes, hipStream_t s) { auto* r = (Rec*)p; r->put(4, (char*)dst - r->staged, r->rank_of(src), (int64_t)bytes, (int64_t)(uintptr_t)s); return r->hit(); };
+    b.copy_peer_async = [](void* p, void* dst, int dd, const void* src, int sd, size_t bytes, hipStream_t s) {
+        auto* r = (Rec*)p; r->put(5, (char*)dst - r->staged, r->rank_of(src), (int64_t)bytes, (int64_t)(uintptr_t)s, dd, sd); return r->hit(); };
+    b.group_start = [](void* p) { auto* r = (Rec*)p; r->put(6); return r->hit(); };
+    b.group_end = [](void* p) { auto* r = (Rec*)p; r->put(7); return r->hit(); };
+    b.send = [](void* p, const void* buf, size_t count, int fp64, int peer, void* comm, hipStream_t s) {
+        auto* r = (Rec*)p; r->put(8, r->rank_of(buf), (int64_t)count, fp64, peer, (int64_t)(uintptr_t)comm, (int64_t)(uintptr_t)s); return r->hit(); };
+    b.recv = [](void* p, void* buf, size_t count, int fp64, int peer, void* comm, hipStream_t s) {
+        auto* r = (Rec*)p; r->put(9, (char*)buf - r->staged, (int64_t)count, fp64, peer, (int64_t)(uintptr_t)comm, (int64_t)(uintptr_t)s); return r->hit(); };
+    (void)id;
+    GatherInputs in;
+    in.n = n; in.mode = mode; in.W = W; in.fp64 = precision == 64;
+    in.dev = devices; in.rows = rows; in.offsets = offsets.data(); in.fb = rec.fb.data(); in.staged = rec.staged;
+    in.stream = stream.data(); in.done = done.data(); in.g0 = (hipEvent_t)(uintptr_t)99; in.comms = comms.data();
+    const char* where = "";
+    *schedule_rc = run_gather_schedule(in, b, where);
+    (void)es;
+    const size_t nrec = rec.v.size() / 8;
+    if (nrec > cap_records) return RTIOW_E_BADARG;
+    std::memcpy(records, rec.v.data(), rec.v.size() * sizeof(int64_t));
+    return (int)nrec;
+}
 
 }  // extern "C"

@@ -35,6 +35,7 @@
 #include <cstdio>
 #include <array>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -65,6 +66,11 @@
 extern "C" {
 
 int rtiow_abi_version(void) { return RTIOW_ABI_VERSION; }
+
+#ifndef RTIOW_BUILD_ID
+#define RTIOW_BUILD_ID "unknown"
+#endif
+const char* rtiow_build_id(void) { return RTIOW_BUILD_ID; }
 
 #ifdef RTIOW_PATH_STATS
 // stats build only: read (reset != 0: clear) the execution profile, 2 words per region

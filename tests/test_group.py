@@ -116,6 +116,39 @@ def test_group_matches_single_handle_at_headline_geometry(native):
 
 
 @pytest.mark.gpu
+def test_group_over_distinct_devices(native):
+    """The exchange BETWEEN devices -- ncclSend/ncclRecv on communicator ranks >= 1, hipMemcpyPeerAsync with its
+    cross-device events, peer access enabled for an explicit RTIOW_GATHER_PEER as for the fallback -- needs a node
+    with at least two GPUs; the one-GPU boxes this repo has been developed on skip it (N > 1 transports
+    are unexecuted there; their schedule is pinned on the CPU by tests/test_group_schedule.py).  Both precisions, a
+    frame height that is not a multiple of the strip height, two renders through one group, bit for bit against
+    the single-handle render."""
+    import torch
+    rt = native
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip("needs >= 2 GPUs (this box has %d)" % ndev)
+    n = min(ndev, 8)
+    for prec, W, H, S, B, strip in ((32, 320, 197, 8, 25, 8), (64, 200, 101, 4, 25, 2)):
+        with rt.Renderer(0, prec) as r:
+            r.set_camera(rt.camera(prec, W, H, S, B)); r.set_scene(rt.build_scene(3, prec)); r.init_rng(1227)
+            r.render(0)
+            want = r.read_framebuffer()
+        for gather in (rt.GATHER_RCCL, rt.GATHER_PEER):
+            with rt.RendererGroup(n, prec, strip, gather, list(range(n))) as g:
+                g.set_camera(rt.camera(prec, W, H, S, B)); g.set_scene(rt.build_scene(3, prec)); g.init_rng(1227)
+                g.render(0)
+                a = g.read_framebuffer()
+                g.render(0)
+                b = g.read_framebuffer()
+                st = g.stats()
+            assert _same_bits(a, want) and _same_bits(b, want), (prec, gather)
+            assert st["gather_mode"] == gather and st["gather_bytes"] == W * H * 3 * (prec // 8) and st["gather_ms"] > 0
+            if gather == rt.GATHER_PEER:
+                assert 0 <= st["peer_links"] <= n - 1
+
+
+@pytest.mark.gpu
 def test_executable_gpus_flag(native, oracle, tmp_path):
     """--gpus 1 (group path, RCCL) and --devices 0,0,0 (three ranks on the one GPU, copies): same stdout
     format, same file name, same P3 bytes as the single-handle path and as the oracle."""
@@ -134,6 +167,7 @@ def test_executable_gpus_flag(native, oracle, tmp_path):
         assert open(str(d / name), "rb").read() == rt.format_ppm(want), extra
         st = json.loads(r.stderr.strip().splitlines()[-1])
         assert st["gather"] == transport and st["gather_bytes"] == 160 * 96 * 12 and len(st["kernel_ms"]) == st["gpus"]
+        assert st["wall_ms"]["group_create"] > 0 and st["end_to_end_excludes"] == "group_create"
         assert max(st["kernel_ms"]) == pytest.approx(render_ms, abs=1e-5)
     # more GPUs than the box has: the reference's error convention (message on stderr, non-zero exit, empty stdout)
     import torch
@@ -164,3 +198,32 @@ def test_bench_under_torchrun_runs_rccl_at_world_size_one(native):
     assert sd["gather_ms"] is not None and sd["gather_ms"] > 0 and sd["gather_bytes_total"] == 256 * 144 * 12
     assert len(sd["kernel_ms_per_rank"]) == 1 and len(sd["gather_ms_per_rank"]) == 1
     assert 0 < sd["floor_ms"] <= d["ms_per_step"] and sd["longest_chain_segments"] > 64 and 0.3 < sd["lone_ray_trip_us"] < 50
+
+
+@pytest.mark.gpu
+def test_bench_without_a_launcher_drives_the_group(native):
+    """`python3 bench.py --gpus N` launched like the N = 1 bench (no torch.distributed.run): the in-library group renders the
+    strips and exchanges them once per step.  With one GPU the two ranks share device 0 (--devices 0,0)."""
+    import sys
+    from tests.conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0", "--steps", "3", "--warmup", "1",
+                        "--width", "256", "--height", "144", "--samples", "64", "--bounces", "10"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3 and "rtiow_group" in d["config"]["backend"]
+    assert abs(d["value"] - 256 * 144 * 64 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]
+    sd = d["scaling_detail"]
+    assert len(sd["kernel_ms_per_rank"]) == 2 and all(x > 0 for x in sd["kernel_ms_per_rank"])
+    assert sd["gather_ms"] > 0 and sd["gather_bytes_total"] == 256 * 144 * 12 and "peer" in sd["gather_transport"]
+    assert d["kernel_ms_mean"] == pytest.approx(max(sd["kernel_ms_per_rank"]), rel=0.25)
+    assert 1.5 < d["segments_per_ray"] < 3.5 and d["roofline"]["frac"] is None and "cpu_baseline" not in d
+    # more ranks than the node has GPUs, no --devices: a loud failure, no line
+    import torch
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(torch.cuda.device_count() + 1), "--steps", "1", "--warmup", "0",
+                        "--width", "64", "--height", "64", "--samples", "4"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+

@@ -1,0 +1,176 @@
+"""The exchange of the in-library multi-GPU group (csrc/rtiow_group.hip) as a SCHEDULE, checked without GPUs.
+
+rtiow_group_gather asks HIP and RCCL for everything through one table of calls (GatherBackend); the debug hook
+rtiow_debug_gather_schedule runs the same schedule function against a recorder.  No N > 1 transport has run on
+hardware yet (a one-GPU box cannot), so what CAN be pinned here is pinned: which call, on which device, stream and
+communicator, with which counts and offsets, in which order, fenced by which events -- for the RCCL send/recv form
+and for the peer-copy form, including ranks without rows and failing calls.
+
+New work: the reference is single-GPU (/root/reference/src/GlobalFloatCUDAInOneWeekend/main.cu:81).
+"""
+import numpy as np
+import pytest
+
+SET_DEVICE, WAIT, RECORD, COPY, COPY_PEER, GROUP_START, GROUP_END, SEND, RECV = range(1, 10)
+G0 = 99
+
+
+def stream(k):
+    return 1 + k
+
+
+def done(k):
+    return 100 + k
+
+
+def comm(k):
+    return 200 + k
+
+
+def rows_of(native, H, n, strip):
+    return [len(native.shard_rows(H, r, n, strip)) for r in range(n)]
+
+
+def offsets_bytes(rows, W, es):
+    off, out = 0, []
+    for r in rows:
+        out.append(off * es)
+        off += r * W * 3
+    return out
+
+
+def device_at(rec, index):
+    """The device in effect when call `index` was made (field 1 of every record, as tracked by the recorder)."""
+    return rec[index][1]
+
+
+@pytest.mark.parametrize("prec", (32, 64))
+@pytest.mark.parametrize("n,H,strip", ((8, 1080, 2), (4, 1080, 2), (2, 1080, 8), (3, 100, 7), (5, 11, 8)))
+def test_rccl_schedule_counts_offsets_comms_and_fences(native, n, H, strip, prec):
+    W, es = 1920, prec // 8
+    devices = list(range(n))
+    rows = rows_of(native, H, n, strip)
+    assert sum(rows) == H
+    rec, rc = native.debug_gather_schedule(devices, rows, W, prec, native.GATHER_RCCL)
+    assert rc == 0
+    ops = [r[0] for r in rec]
+    # ---- opening fence on device 0: stream 0 waits for every other rank's render, THEN records g0
+    i_g0 = next(i for i, r in enumerate(rec) if r[0] == RECORD and r[2] == G0)
+    assert rec[0][:3] == (SET_DEVICE, -1, 0)
+    waits0 = [r for r in rec[:i_g0] if r[0] == WAIT]
+    assert [(r[2], r[3]) for r in waits0] == [(stream(0), done(k)) for k in range(1, n)]
+    assert rec[i_g0][3] == stream(0) and device_at(rec, i_g0) == 0
+    # ---- every other rank's stream waits for g0 on ITS device before the group opens
+    i_start, i_end = ops.index(GROUP_START), ops.index(GROUP_END)
+    assert ops.count(GROUP_START) == ops.count(GROUP_END) == 1 and i_g0 < i_start < i_end
+    pre = rec[i_g0 + 1:i_start]
+    assert [r[0] for r in pre] == [SET_DEVICE, WAIT] * (n - 1)
+    for k in range(1, n):
+        sd, w = pre[2 * (k - 1)], pre[2 * (k - 1) + 1]
+        assert sd[2] == devices[k] and (w[2], w[3]) == (stream(k), G0) and w[1] == devices[k]
+    # ---- inside the group: one send + one recv per rank WITH rows, in rank order; nothing else
+    inside = rec[i_start + 1:i_end]
+    live = [k for k in range(n) if rows[k] > 0]
+    assert [r[0] for r in inside] == [SEND, RECV] * len(live)
+    off = offsets_bytes(rows, W, es)
+    for j, k in enumerate(live):
+        s, r = inside[2 * j], inside[2 * j + 1]
+        count = rows[k] * W * 3
+        # send: rank k's framebuffer, its own communicator and stream, to peer 0
+        assert s[2:] == (k, count, int(prec == 64), 0, comm(k), stream(k))
+        # recv: rank 0's communicator and stream, from peer k, into rank k's block of the staging buffer
+        assert r[2:] == (off[k], count, int(prec == 64), k, comm(0), stream(0))
+    # blocks tile the staging buffer exactly (rank-major, no gaps, no overlap)
+    ends = [off[k] + rows[k] * W * 3 * es for k in live]
+    assert [off[k] for k in live][1:] == ends[:-1] and ends[-1] == W * H * 3 * es
+    # ---- the schedule ends with device 0 current (the caller launches the de-interleave there)
+    assert rec[-1][:3] == (SET_DEVICE, rec[-2][1] if len(rec) > 1 else -1, 0) and ops[i_end + 1:] == [SET_DEVICE]
+    assert COPY not in ops and COPY_PEER not in ops
+
+
+@pytest.mark.parametrize("prec", (32, 64))
+def test_peer_schedule_event_choreography(native, prec):
+    """Distinct devices: rank k's copy runs on ITS device and stream, after g0; done[k] is re-recorded behind the copy
+    and stream 0 waits for it.  Ranks that share device 0 (and rank 0) copy on stream 0."""
+    W, H, strip, es = 640, 90, 4, prec // 8
+    devices = [0, 1, 2, 0, 3]                       # rank 3 shares device 0
+    n = len(devices)
+    rows = rows_of(native, H, n, strip)
+    rec, rc = native.debug_gather_schedule(devices, rows, W, prec, native.GATHER_PEER)
+    assert rc == 0
+    ops = [r[0] for r in rec]
+    assert GROUP_START not in ops and SEND not in ops and RECV not in ops
+    i_g0 = next(i for i, r in enumerate(rec) if r[0] == RECORD and r[2] == G0)
+    assert [(r[2], r[3]) for r in rec[:i_g0] if r[0] == WAIT] == [(stream(0), done(k)) for k in range(1, n)]
+    off = offsets_bytes(rows, W, es)
+    body = rec[i_g0 + 1:-1]
+    pos = 0
+    for k in range(n):
+        nbytes = rows[k] * W * 3 * es
+        if k == 0 or devices[k] == devices[0]:
+            sd, cp = body[pos], body[pos + 1]
+            assert sd[:3] == (SET_DEVICE, sd[1], 0)
+            assert cp[0] == COPY and cp[1] == 0 and cp[2:6] == (off[k], k, nbytes, stream(0))
+            pos += 2
+        else:
+            sd, w, cp, ev, sd0, w0 = body[pos:pos + 6]
+            assert sd[0] == SET_DEVICE and sd[2] == devices[k]
+            assert w[0] == WAIT and (w[2], w[3]) == (stream(k), G0) and w[1] == devices[k]          # not before the timed region opens
+            assert cp[0] == COPY_PEER and cp[1] == devices[k] and cp[2:] == (off[k], k, nbytes, stream(k), 0, devices[k])
+            assert ev[0] == RECORD and (ev[2], ev[3]) == (done(k), stream(k)) and ev[1] == devices[k]   # behind the copy, same stream
+            assert sd0[0] == SET_DEVICE and sd0[2] == 0
+            assert w0[0] == WAIT and (w0[2], w0[3]) == (stream(0), done(k)) and w0[1] == 0              # stream 0 sees the block
+            pos += 6
+    assert pos == len(body) and rec[-1][0] == SET_DEVICE and rec[-1][2] == 0
+
+
+def test_ranks_without_rows_take_no_part(native):
+    """More ranks than strips: the idle ranks neither send nor are received from (RCCL), nor copy (peer)."""
+    W, H, strip, n = 64, 10, 4, 6                   # 3 strips: ranks 3..5 have no rows
+    rows = rows_of(native, H, n, strip)
+    assert rows == [4, 4, 2, 0, 0, 0]
+    rec, rc = native.debug_gather_schedule(list(range(n)), rows, W, 32, native.GATHER_RCCL)
+    assert rc == 0
+    assert sorted(r[2] for r in rec if r[0] == SEND) == [0, 1, 2] and sorted(r[5] for r in rec if r[0] == RECV) == [0, 1, 2]
+    rec, rc = native.debug_gather_schedule(list(range(n)), rows, W, 32, native.GATHER_PEER)
+    assert rc == 0
+    assert [r[3] for r in rec if r[0] in (COPY, COPY_PEER)] == [0, 1, 2]
+    # the opening fence still covers every rank's render: an idle rank's done event is recorded by rtiow_group_render all the same
+    i_g0 = next(i for i, r in enumerate(rec) if r[0] == RECORD and r[2] == G0)
+    assert len([r for r in rec[:i_g0] if r[0] == WAIT]) == n - 1
+
+
+def test_single_rank_group_sends_to_itself(native):
+    """N = 1 is what a one-GPU box executes on hardware (tests/test_group.py): rank 0 sends to itself inside the group."""
+    rec, rc = native.debug_gather_schedule([0], [48], 100, 32, native.GATHER_RCCL)
+    assert rc == 0
+    assert [r[0] for r in rec] == [SET_DEVICE, RECORD, GROUP_START, SEND, RECV, GROUP_END, SET_DEVICE]
+    assert rec[3][2:] == (0, 48 * 100 * 3, 0, 0, comm(0), stream(0)) and rec[4][2:] == (0, 48 * 100 * 3, 0, 0, comm(0), stream(0))
+
+
+def test_a_failing_call_stops_the_schedule_and_closes_the_group(native):
+    devices, rows, W = [0, 1, 2, 3], [8, 8, 8, 8], 32
+    full, _ = native.debug_gather_schedule(devices, rows, W, 32, native.GATHER_RCCL)
+    ops_full = [r[0] for r in full]
+    for fail_at in range(len(full)):
+        rec, rc = native.debug_gather_schedule(devices, rows, W, 32, native.GATHER_RCCL, fail_at)
+        ops = [r[0] for r in rec]
+        assert rc == 999
+        if ops_full[fail_at] in (GROUP_START, SEND, RECV):
+            # inside an open RCCL group a failure still closes the group (ncclGroupEnd), and nothing else follows
+            assert ops == ops_full[:fail_at + 1] + [GROUP_END]
+        else:
+            assert ops == ops_full[:fail_at + 1]
+    full, _ = native.debug_gather_schedule([0, 1, 0], [8, 8, 8], W, 32, native.GATHER_PEER)
+    for fail_at in range(len(full)):
+        rec, rc = native.debug_gather_schedule([0, 1, 0], [8, 8, 8], W, 32, native.GATHER_PEER, fail_at)
+        assert rc == 999 and [r[0] for r in rec] == [r[0] for r in full][:fail_at + 1]
+
+
+def test_schedule_hook_rejects_bad_arguments(native):
+    with pytest.raises(native.RtiowError):
+        native.debug_gather_schedule([0, 1], [4, 4], 0, 32, native.GATHER_RCCL)
+    with pytest.raises(native.RtiowError):
+        native.debug_gather_schedule([0, 1], [4, 4], 8, 16, native.GATHER_RCCL)
+    with pytest.raises(native.RtiowError):
+        native.debug_gather_schedule([0, 1], [4, 4], 8, 32, native.GATHER_AUTO)
