@@ -274,6 +274,7 @@ def emit(json_fd, args, ctx):
         "step": {"launches": "prepass (%d spp) + cost sort + main" % st["prepass_samples"] if st["phases"] == 2 else "main",
                  "kernel_ms_mean": round(kms, 4), "prepass_ms": round(float(st["prepass_ms"]), 4),
                  "scene_prepare_ms": round(float(st["scene_prepare_ms"]), 3),   # host: screening table + grid plan, once per scene, before the first render's start event
+                 "place_ms": round(float(st["place_ms"]), 4), "staged_stores": int(st["staged_stores"]),   # sorted schedule: pixels stored in slot order, place_pixels_kernel writes the image in whole lines
                  "solo_waves": int(st["solo_waves"]),   # > 0: a partly filled GPU (shard, small frame), render_solo_kernel
                  "algorithmic_flops": flops_step, "algorithmic_TFLOPs": round(flops_step / (kms * 1e-3) / 1e12, 3),
                  "algorithmic_frac": round(flops_step / (kms * 1e-3) / 1e12 / peak, 4)},

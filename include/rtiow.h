@@ -121,6 +121,11 @@ typedef struct {
      * it, BEFORE the start event of that render: like the reference's scene set-up (main.cu:148-321) it is outside
      * render_only and inside end_to_end.  0 when the last scene needed no tables (scalar / exact sources). */
     double   scene_prepare_ms;
+    /* RTIOW_SCHED_SORTED: 1 when the main launch stored finished pixels in slot order into a staging buffer and
+     * place_pixels_kernel wrote the image in whole lines (coalesced framebuffer writes); place_ms = HIP-event time of
+     * that kernel in the last timed render (inside render_ms, outside main_ms). */
+    int32_t  staged_stores, reserved0;
+    double   place_ms;
 } rtiow_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------

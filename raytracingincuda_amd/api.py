@@ -69,7 +69,8 @@ class Stats(ctypes.Structure):
                 ("max_chain_prepass", ctypes.c_uint64), ("max_chain_main", ctypes.c_uint64),
                 ("grid_nx", ctypes.c_int32), ("grid_nz", ctypes.c_int32), ("grid_registered", ctypes.c_int32),
                 ("grid_direct", ctypes.c_int32), ("grid_cell", ctypes.c_double),
-                ("solo_waves", ctypes.c_int32), ("solo_lanes", ctypes.c_int32), ("scene_prepare_ms", ctypes.c_double)]
+                ("solo_waves", ctypes.c_int32), ("solo_lanes", ctypes.c_int32), ("scene_prepare_ms", ctypes.c_double),
+                ("staged_stores", ctypes.c_int32), ("reserved0", ctypes.c_int32), ("place_ms", ctypes.c_double)]
 
 
 class GroupStats(ctypes.Structure):

@@ -83,6 +83,18 @@ def build_stats(verbose=True):
     return out
 
 
+def build_variant(name, defines=(), csrc=None, verbose=True):
+    """A/B builds of the HIP library (lib/ab/<name>.so; scripts/ab_libs.py, scripts/pmc_passes.py via RTIOW_HIP_LIBRARY):
+    the same flags as the product plus `defines`; `csrc` = another source tree (e.g. an older commit exported with git archive)."""
+    out_dir = os.path.join(LIB, "ab")
+    os.makedirs(out_dir, exist_ok=True)
+    src = csrc or CSRC
+    out = os.path.join(out_dir, name + ".so")
+    flags = [f for f in HIP_FLAGS if not f.startswith("-I")] + ["-I" + (os.path.join(os.path.dirname(os.path.dirname(src)), "include") if csrc else INC)]
+    _run([_hipcc()] + flags + list(defines) + ['-DRTIOW_BUILD_ID="variant:%s"' % name, "-o", out, os.path.join(src, "rtiow_hip.hip"), os.path.join(src, "rtiow_group.hip"), "-ldl"], verbose)
+    return out
+
+
 def build(force=False, verbose=True):
     os.makedirs(LIB, exist_ok=True)
     os.makedirs(BIN, exist_ok=True)

@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(COST_BINS) cost_scan_kernel(const unsigned* __
 constexpr int SCATTER_PER_THREAD = 4;
 __global__ void __launch_bounds__(1024) cost_scatter_kernel(const uint32_t* __restrict__ cost, int W, int rows, const unsigned* __restrict__ start,
                                                             unsigned* __restrict__ fill, int* __restrict__ order, int pools_per_block, int total_pools, int group,
-                                                            int solo_slots) {
+                                                            int solo_slots, int* __restrict__ slot_of) {
     __shared__ unsigned local[COST_BINS];        // block histogram, then the running rank inside the reserved range
     __shared__ unsigned base[COST_BINS];
     for (int b = threadIdx.x; b < COST_BINS; b += blockDim.x) local[b] = 0;
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(1024) cost_scatter_kernel(const uint32_t* __re
         if (bins[u] < 0) continue;
         const int k = pix[u];
         int r = (int)(base[bins[u]] + atomicAdd(&local[bins[u]], 1u));   // sorted rank (order inside a bin is immaterial)
-        if (r < solo_slots) { order[r] = k; continue; }              // the heaviest pixels: slot = rank, handed to the solo waves
+        if (r < solo_slots) { order[r] = k; if (slot_of) slot_of[k] = r; continue; }   // the heaviest pixels: slot = rank, handed to the solo waves
         r -= solo_slots;
         const int blk = r / per_block, q = r - blk * per_block;
         const int pools_here = (blk + 1) * pools_per_block <= total_pools ? pools_per_block : total_pools - blk * pools_per_block;
@@ -153,7 +153,20 @@ __global__ void __launch_bounds__(1024) cost_scatter_kernel(const uint32_t* __re
         const int pool = blk * pools_per_block + g % pools_here;
         const int lane_slot = (g / pools_here) * group + j;
         order[solo_slots + pool * POOL + lane_slot] = k;
+        if (slot_of) slot_of[k] = solo_slots + pool * POOL + lane_slot;       // the inverse, for place_pixels_kernel
     }
+}
+
+// Staging buffer in slot order -> image: one thread per pixel in IMAGE order reads its slot (coalesced), gathers the
+// 3 T of its pixel from the staging buffer (25 MB at 1080p: L2 / Infinity-Cache resident, written microseconds ago)
+// and writes the image in whole lines.  ~20 us at 1920 x 1080.
+template <class T>
+__global__ void __launch_bounds__(256) place_pixels_kernel(const T* __restrict__ staged, const int* __restrict__ slot_of, T* __restrict__ fb, int npix) {
+    const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (k >= npix) return;
+    const T* src = staged + 3 * (size_t)slot_of[k];
+    T* dst = fb + 3 * (size_t)k;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
 }
 
 }  // namespace

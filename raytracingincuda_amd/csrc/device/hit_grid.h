@@ -111,7 +111,8 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
     const auto& g = grid_of(p);
     REGION_BEGIN(setup);
     // ---- which rays the registration margins cover
-    const float fx = (float)(O.x - p.ctr_x), fy = (float)(O.y - p.ctr_y), fz = (float)(O.z - p.ctr_z);
+    const auto& sc = screen_of(p);
+    const float fx = (float)(O.x - (T)sc.ctr_x), fy = (float)(O.y - (T)sc.ctr_y), fz = (float)(O.z - (T)sc.ctr_z);
     const float k2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
     const float af = (float)a;
     const bool sane = af > 1e-30f && af < 1e30f && k2 < 1e30f;        // false for NaN as well

@@ -153,14 +153,15 @@ __device__ __forceinline__ void exact_sphere_test(const double* g, int s, V3<dou
 template <class T>
 __device__ __forceinline__ void hit_world_screened(const RenderParams<T>& p, const T* lds_exact, const float* lds_screen,
                                                    V3<T> O, V3<T> D, T a, T& closest, int& hit) {
-    float ox = (float)(O.x - p.ctr_x), oy = (float)(O.y - p.ctr_y), oz = (float)(O.z - p.ctr_z);
+    const auto& sc = screen_of(p);
+    float ox = (float)(O.x - (T)sc.ctr_x), oy = (float)(O.y - (T)sc.ctr_y), oz = (float)(O.z - (T)sc.ctr_z);
     float dx = (float)D.x, dy = (float)D.y, dz = (float)D.z;
     const float af = sizeof(T) == 4 ? (float)a : __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
     const float rs = __builtin_amdgcn_rsqf(af);   // screen only: |d^| = 1 +- 2^-22
     dx *= rs; dy *= rs; dz *= rs;
     float nk1 = -__builtin_fmaf(dz, oz, __builtin_fmaf(dy, oy, dx * ox));
     float k2 = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
-    k2 = k2 - 7.62939453125e-06f * __builtin_fmaf((float)p.omax2, fast_sqrt(k2), k2);   // - 2^-17 (2 Cmax |O'| + |O'|^2); p.omax2 holds 2 Cmax (1 + 2^-20): raw sqrt
+    k2 = k2 - 7.62939453125e-06f * __builtin_fmaf((float)(T)sc.omax2, fast_sqrt(k2), k2);   // - 2^-17 (2 Cmax |O'| + |O'|^2); omax2 holds 2 Cmax (1 + 2^-20): raw sqrt
     float mx = -2.0f * ox, my = -2.0f * oy, mz = -2.0f * oz;
     asm volatile("" : "+v"(nk1), "+v"(k2), "+v"(mx), "+v"(my), "+v"(mz), "+v"(dx), "+v"(dy), "+v"(dz));
     const v2f vnk1 = {nk1, nk1}, vk2 = {k2, k2}, vmx = {mx, mx}, vmy = {my, my}, vmz = {mz, mz};

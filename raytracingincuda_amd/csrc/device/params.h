@@ -55,6 +55,12 @@ template <class T> struct ColdParams {
     unsigned char* __restrict__ mid_out;        // prepass: park the state (nullptr: final launch, the pixel is stored)
     uint32_t* __restrict__ cost_out;  // prepass only: segments the pixel ran in this launch
     const int* __restrict__ order;    // slot -> local pixel (or -1), nullptr: 8x8 tiles bottom-up
+    // Main launch of the sorted schedule: a finished pixel is stored at its SLOT in a staging buffer (`fb` then points
+    // there), not at its place in the image.  Lanes store 12-byte pixels whenever they finish; in image order the
+    // partial lines of neighbouring pixels come from different waves on different XCDs (1.8 x write amplification,
+    // measured); a wave's slots are 768 contiguous bytes that only that wave writes, and place_pixels_kernel then
+    // writes the image in whole lines.
+    int stage_by_slot;
     int total_slots;
     int first_pools;                  // 1: wave w starts with pool w (the work counter then starts at the wave count)
     // Solo waves: the first solo_waves*solo_lanes slots of the order (the heaviest pixels) go solo_lanes each to
@@ -63,24 +69,37 @@ template <class T> struct ColdParams {
     unsigned long long* timeline;     // COUNT variant, optional: per wave {t_start, t_exhausted, t_end, iters_normal, iters_coop, pixels, 0, 0}
 };
 
+// The camera (camera.h:10-30 as camera::initialize leaves it): 19 scalars that only gen_primary reads, once per
+// primary ray.  Like the cold part they are re-read from the kernarg segment where they are used (cam_of) instead
+// of occupying 19-38 SGPRs for the whole path loop.
+template <class T> struct CameraParams {
+    V3<T> center, pixel00, du, dv;
+    T defocus_angle;
+    V3<T> ddu, ddv;
+};
+
+// The fp32 screening table and the recentring point of screen and grid: read where hit_world starts (screen_of).
+template <class T> struct ScreenParams {
+    // fp32 screening table (hit_world_screened): recentred centres and q' = |C'|^2 - r^2 - margin,
+    // pair-interleaved like geom_a; staged in LDS behind geom_a (screen_offset bytes)
+    const float* __restrict__ geom_s;
+    T ctr_x, ctr_y, ctr_z, omax2;     // recentring point; omax2 = 2 Cmax of the per-ray margin term
+    // everything the shade step needs about the sphere that was hit, 12 T per sphere:
+    // {cx,cy,cz,1/r | albedo r,g,b,fuzz (dielectric: Schlick r0^2 front, back, -, -) | eta, 1/eta, material type, 0};
+    // the global copy is read only when the records do not ride along in LDS (shade_in_lds == 0)
+    const T* __restrict__ shade_tbl;
+};
+
 template <class T> struct RenderParams {
     int B, s_end;                     // bounce limit; this launch renders samples [cold.s_begin, s_end)
     int lane_cap;                     // lanes of a wave that take pixels (64; fewer when the launch is underfilled, see launch_render)
     int range_flags;                  // host-checked operand ranges.  bit 0 (primary_rays_in_range): |D|^2 of every primary ray lies well
                                       // inside [2^-80, 2^80]; bit 1 (scene_in_range): every coordinate of spheres and lens is below 2^18
-    V3<T> center, pixel00, du, dv;
-    T defocus_angle;
-    V3<T> ddu, ddv;
+    CameraParams<T> cam;              // read through cam_of
     int n, n_padded;                  // spheres, and the table length padded to a multiple of 4
     const T* __restrict__ geom_a;     // [n_padded][4] cx,cy,cz,r*r (sphere loop; padding never hits)
-    // fp32 screening table (hit_world_screened): recentred centres and q' = |C'|^2 - r^2 - margin,
-    // pair-interleaved like geom_a; staged in LDS behind geom_a (screen_offset bytes)
-    const float* __restrict__ geom_s;
     int use_screen, screen_offset;
-    T ctr_x, ctr_y, ctr_z, omax2;     // recentring point; omax2 = 2 Cmax of the per-ray margin term
-    // everything the shade step needs about the sphere that was hit, 12 T per sphere:
-    // {cx,cy,cz,1/r | albedo r,g,b,fuzz | eta, 1/eta, material type, 0}
-    const T* __restrict__ shade_tbl;
+    ScreenParams<T> screen;           // read through screen_of
     int shade_in_lds;                 // 1: the table is staged behind the loop table in LDS (shade_offset bytes)
     int shade_offset;
     int coop_offset;                  // SCHED_PERSISTENT: byte offset of the per-wave coop scratch in LDS
@@ -98,6 +117,20 @@ __device__ __forceinline__ const __attribute__((address_space(4))) ColdParams<T>
     kptr k = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(k));
     return *(const __attribute__((address_space(4))) ColdParams<T>*)(k + offsetof(RenderParams<T>, cold));
+}
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(4))) CameraParams<T>& cam_of(const RenderParams<T>&) {
+    typedef const __attribute__((address_space(4))) char* kptr;
+    kptr k = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return *(const __attribute__((address_space(4))) CameraParams<T>*)(k + offsetof(RenderParams<T>, cam));
+}
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(4))) ScreenParams<T>& screen_of(const RenderParams<T>&) {
+    typedef const __attribute__((address_space(4))) char* kptr;
+    kptr k = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return *(const __attribute__((address_space(4))) ScreenParams<T>*)(k + offsetof(RenderParams<T>, screen));
 }
 // Same for the grid description: ~25 scalars that only hit_world_grid needs, loaded at its entry.
 template <class T>

@@ -26,12 +26,14 @@ __device__ __forceinline__ T* stage_scene(const RenderParams<T>& p) {
             for (int k = threadIdx.x; k < p.n_padded * 4; k += blockDim.x) lds_geom[k] = p.geom_a[k];
             if (p.use_screen) {
                 float* lds_screen = reinterpret_cast<float*>(smem_raw + p.screen_offset);   // fp32 for both precisions
-                for (int k = threadIdx.x; k < p.n_padded * 4; k += blockDim.x) lds_screen[k] = p.geom_s[k];
+                const float* geom_s = p.screen.geom_s;   // kernel entry: nothing is live yet
+                for (int k = threadIdx.x; k < p.n_padded * 4; k += blockDim.x) lds_screen[k] = geom_s[k];
             }
         }
         if (p.shade_in_lds) {
             T* lds_shade = reinterpret_cast<T*>(smem_raw + p.shade_offset);
-            for (int k = threadIdx.x; k < p.n * 12; k += blockDim.x) lds_shade[k] = p.shade_tbl[k];
+            const T* tbl = p.screen.shade_tbl;
+            for (int k = threadIdx.x; k < p.n * 12; k += blockDim.x) lds_shade[k] = tbl[k];
         }
         if (SRC == RTIOW_SCENE_LDS && p.use_grid) {
             uint32_t* dst = reinterpret_cast<uint32_t*>(smem_raw + p.grid.cells_offset);

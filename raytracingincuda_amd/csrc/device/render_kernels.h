@@ -181,6 +181,7 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
                         }
                         st.sample = c.s_begin; st.depth = 0;
                         cost = 0;
+                        if (c.stage_by_slot) lp = (size_t)slot;      // where this pixel will be stored (ColdParams::stage_by_slot); the state is loaded
                         if (COUNT) ++n_pixels;
                         if (c.s_begin < S) { alive = true; fresh = true; }
                         else { finish_pixel<T>(c, lp, st, cost); want = true; }   // nothing to render in this launch

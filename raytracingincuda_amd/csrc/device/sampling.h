@@ -33,12 +33,14 @@ template <class T>
 __device__ __forceinline__ void gen_primary(const RenderParams<T>& p, int i, int j, Rng& s,
                                             V3<T>& O, V3<T>& D, T& sky_uy) {
     PATH_STAT(PS_GEN_PRIMARY);
+    const auto& c = cam_of(p);                   // scalar loads from the kernarg segment, here
     T ox = Real<T>::uniform(s) - (T)0.5;
     T oy = Real<T>::uniform(s) - (T)0.5;
     T fi = (T)i + ox, fj = (T)j + oy;
-    V3<T> ps = madd3(fj, p.dv, madd3(fi, p.du, p.pixel00));
-    V3<T> org = p.center;
-    if (!(p.defocus_angle <= (T)0)) {
+    V3<T> ps = madd3(fj, V3<T>{c.dv.x, c.dv.y, c.dv.z}, madd3(fi, V3<T>{c.du.x, c.du.y, c.du.z}, V3<T>{c.pixel00.x, c.pixel00.y, c.pixel00.z}));
+    const V3<T> ctr = {c.center.x, c.center.y, c.center.z};
+    V3<T> org = ctr;
+    if (!((T)c.defocus_angle <= (T)0)) {
         T px, py;
         for (;;) {
             PATH_STAT(PS_DISK_ROUND);
@@ -48,7 +50,7 @@ __device__ __forceinline__ void gen_primary(const RenderParams<T>& p, int i, int
             py = RT_FMA((T)2, u1, (T)-1);
             if (RT_FMA(py, py, px * px) < (T)1) break;
         }
-        org = madd3(py, p.ddv, madd3(px, p.ddu, p.center));
+        org = madd3(py, V3<T>{c.ddv.x, c.ddv.y, c.ddv.z}, madd3(px, V3<T>{c.ddu.x, c.ddu.y, c.ddu.z}, ctr));
     }
     O = org;
     D = {ps.x - org.x, ps.y - org.y, ps.z - org.z};

@@ -39,8 +39,9 @@ __device__ __forceinline__ bool shade_step(const RenderParams<T>& p, const T* ld
 #pragma unroll
         for (int k = 0; k < 12; ++k) rec[k] = lds_shade[12 * hit + k];
     } else {
+        const T* tbl = screen_of(p).shade_tbl;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) rec[k] = p.shade_tbl[12 * (size_t)hit + k];
+        for (int k = 0; k < 12; ++k) rec[k] = tbl[12 * (size_t)hit + k];
     }
     const V3<T> C = {rec[0], rec[1], rec[2]};
     const T inv_r = rec[3];

@@ -8,7 +8,7 @@ struct rtiow_handle_s {
     int precision = 32;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_a = nullptr, ev_b = nullptr;   // ev_a: prepass done, ev_b: main launch starts
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;   // ev_a: prepass done, ev_b: main launch starts, ev_c: main launch done (place_pixels_kernel follows)
     bool time_phases = false;
     bool render_pending = false;                  // rtiow_render_async recorded its stop event, rtiow_render_wait has not read it yet
     std::string err;
@@ -49,6 +49,8 @@ struct rtiow_handle_s {
     uint32_t* cost = nullptr; size_t cost_bytes = 0;
     uint32_t* cost_rank = nullptr; size_t cost_rank_bytes = 0;    // the smoothed cost the sort ranks by
     int* order = nullptr; size_t order_bytes = 0;
+    int* slot_of = nullptr; size_t slot_of_bytes = 0;            // SCHED_SORTED: pixel -> slot (the inverse of `order`)
+    unsigned char* staged = nullptr; size_t staged_bytes = 0;             // SCHED_SORTED: finished pixels in slot order (place_pixels_kernel writes the image)
     unsigned* sort_scratch = nullptr; size_t sort_scratch_bytes = 0;
     int waves_per_simd = 0;
     int num_cus = 256;
@@ -154,15 +156,15 @@ RenderParams<T> make_params(const rtiow_handle_s* h, const CAM& c) {
     p.range_flags = primary_rays_in_range(c) | (scene_in_range(h, c) << 1);
     p.cold.W = c.img_width; p.cold.H = c.img_height; p.cold.S = c.samples_per_pixel; p.B = c.max_depth;
     p.cold.pixel_samples_scale = c.pixel_samples_scale;
-    p.center = {c.center[0], c.center[1], c.center[2]};
-    p.pixel00 = {c.pixel00_loc[0], c.pixel00_loc[1], c.pixel00_loc[2]};
-    p.du = {c.pixel_delta_u[0], c.pixel_delta_u[1], c.pixel_delta_u[2]};
-    p.dv = {c.pixel_delta_v[0], c.pixel_delta_v[1], c.pixel_delta_v[2]};
-    p.defocus_angle = c.defocus_angle;
-    p.ddu = {c.defocus_disk_u[0], c.defocus_disk_u[1], c.defocus_disk_u[2]};
-    p.ddv = {c.defocus_disk_v[0], c.defocus_disk_v[1], c.defocus_disk_v[2]};
+    p.cam.center = {c.center[0], c.center[1], c.center[2]};
+    p.cam.pixel00 = {c.pixel00_loc[0], c.pixel00_loc[1], c.pixel00_loc[2]};
+    p.cam.du = {c.pixel_delta_u[0], c.pixel_delta_u[1], c.pixel_delta_u[2]};
+    p.cam.dv = {c.pixel_delta_v[0], c.pixel_delta_v[1], c.pixel_delta_v[2]};
+    p.cam.defocus_angle = c.defocus_angle;
+    p.cam.ddu = {c.defocus_disk_u[0], c.defocus_disk_u[1], c.defocus_disk_u[2]};
+    p.cam.ddv = {c.defocus_disk_v[0], c.defocus_disk_v[1], c.defocus_disk_v[2]};
     p.n = h->n; p.n_padded = h->n_padded;
-    p.geom_a = (const T*)h->geom_a; p.shade_tbl = (const T*)h->shade_tbl;
+    p.geom_a = (const T*)h->geom_a; p.screen.shade_tbl = (const T*)h->shade_tbl;
     p.cold.rng = h->rng; p.cold.fb = (T*)h->fb;
     p.cold.local_rows = h->local_rows; p.cold.rank = h->rank; p.cold.nranks = h->nranks; p.cold.strip_rows = h->strip_rows;
     return p;

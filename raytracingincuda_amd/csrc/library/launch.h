@@ -155,7 +155,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         p.cold.work_counter = h->work_counter;
         p.cold.s_begin = 0; p.s_end = S; p.cold.rng_in = h->rng; p.cold.mid_in = nullptr; p.cold.mid_out = nullptr;
         p.cold.cost_out = nullptr; p.cold.order = nullptr; p.cold.total_slots = (int)tile_slots; p.cold.first_pools = 0;
-        p.cold.solo_waves = 0; p.cold.solo_lanes = 1;
+        p.cold.solo_waves = 0; p.cold.solo_lanes = 1; p.cold.stage_by_slot = 0;
         if (h->schedule == RTIOW_SCHED_SORTED && SA > 0 && npix >= 4096) {
             phases = 2;
             const int total_pools = (npix + POOL - 1) / POOL;
@@ -192,6 +192,17 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             const int solo_slots = solo_waves * solo_lanes;
             if ((rc = ensure_buffer(h, &h->order, &h->order_bytes, ((size_t)total_pools * POOL + (size_t)solo_slots) * sizeof(int)))) return rc;
             if ((rc = ensure_buffer(h, &h->sort_scratch, &h->sort_scratch_bytes, (size_t)3 * COST_BINS * sizeof(unsigned)))) return rc;
+            // finished pixels go to their slot in a staging buffer and place_pixels_kernel writes the image (ColdParams::stage_by_slot)
+#ifdef RTIOW_DIRECT_STORES
+            const bool staged_stores = false;           // A/B build: every lane stores its pixel at its place in the image when it finishes
+#else
+            const bool staged_stores = true;
+#endif
+            const size_t total_slots = (size_t)total_pools * POOL + (size_t)solo_slots;
+            if (staged_stores) {
+                if ((rc = ensure_buffer(h, &h->slot_of, &h->slot_of_bytes, (size_t)npix * sizeof(int)))) return rc;
+                if ((rc = ensure_buffer(h, &h->staged, &h->staged_bytes, total_slots * 3 * sizeof(T)))) return rc;
+            }
             if (prepare_only) return 0;                  // every table and buffer of this configuration now exists
             // ---- prepass: samples [0, SA) in tile order through the same persistent body (the static
             // kernel keeps only ~40 % of its lanes busy over a few samples: 2.6 ms vs 1.4 ms measured
@@ -247,7 +258,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             deal_group = tuned("RTIOW_TUNE_DEAL", deal_group);
             const int scatter_blocks = ((p.cold.W + 63) / 64) * ((h->local_rows + 63) / 64);   // one per 64 x 64 super-tile
             hipLaunchKernelGGL(cost_scatter_kernel, dim3(scatter_blocks), dim3(1024), 0, h->stream, rank_by, p.cold.W, h->local_rows, start, fill, h->order,
-                               pools_per_block, total_pools, deal_group, solo_slots);
+                               pools_per_block, total_pools, deal_group, solo_slots, staged_stores ? h->slot_of : nullptr);
             HIP_TRY(h, hipGetLastError());
             // ---- main launch: samples [SA, S) in that order
             p.cold.s_begin = SA; p.cold.mid_in = h->mid; p.cold.order = h->order;
@@ -255,6 +266,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             p.cold.work_counter = h->work_counter + 1;
             p.cold.first_pools = 1;
             p.cold.solo_waves = solo_waves; p.cold.solo_lanes = solo_lanes;
+            if (staged_stores) { p.cold.stage_by_slot = 1; p.cold.fb = (T*)h->staged; }
             if (solo_waves > 0) {
                 k = k_solo;
                 HIP_TRY(h, hipFuncGetAttributes(&fa, (const void*)k));
@@ -266,7 +278,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         grid = dim3((p.cold.W + bx - 1) / bx, (h->local_rows + by - 1) / by);
         p.cold.s_begin = 0; p.s_end = p.cold.S; p.cold.rng_in = h->rng; p.cold.mid_in = nullptr; p.cold.mid_out = nullptr;
         p.cold.cost_out = nullptr; p.cold.order = nullptr; p.cold.total_slots = 0; p.cold.first_pools = 0; p.cold.work_counter = nullptr;
-        p.cold.solo_waves = 0; p.cold.solo_lanes = 1;
+        p.cold.solo_waves = 0; p.cold.solo_lanes = 1; p.cold.stage_by_slot = 0;
     }
     if (prepare_only) return 0;
     if (seg_counter) {
@@ -278,6 +290,12 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     if (h->time_phases && phases == 2) HIP_TRY(h, hipEventRecord(h->ev_b, h->stream));
     hipLaunchKernelGGL(k, grid, block, lds, h->stream, p);
     HIP_TRY(h, hipGetLastError());
+    if (p.cold.stage_by_slot) {                             // slot order -> image, in whole lines
+        if (h->time_phases) HIP_TRY(h, hipEventRecord(h->ev_c, h->stream));
+        const int npix = p.cold.W * h->local_rows;
+        hipLaunchKernelGGL(place_pixels_kernel<T>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, h->stream, (const T*)h->staged, h->slot_of, (T*)h->fb, npix);
+        HIP_TRY(h, hipGetLastError());
+    }
     if (!seg_counter) {
         h->stats.vgprs = fa.numRegs;
         h->stats.sgprs = 0;
@@ -290,6 +308,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         if (phases == 1) h->stats.prepass_samples = 0;
         h->stats.solo_waves = phases == 2 ? p.cold.solo_waves : 0;
         h->stats.solo_lanes = phases == 2 && p.cold.solo_waves > 0 ? p.cold.solo_lanes : 0;
+        h->stats.staged_stores = p.cold.stage_by_slot;
     }
     return 0;
 }

@@ -281,9 +281,9 @@ int build_grid_tables(rtiow_handle_s* h) {
 
 template <class T>
 void fill_screen_params(RenderParams<T>& p, const rtiow_handle_s* h) {
-    p.geom_s = (const float*)h->geom_s;
+    p.screen.geom_s = (const float*)h->geom_s;
     p.use_screen = ((h->scene_source == RTIOW_SCENE_LDS || h->scene_source == RTIOW_SCENE_GRID) && h->geom_s) ? 1 : 0;
-    p.ctr_x = (T)h->ctr[0]; p.ctr_y = (T)h->ctr[1]; p.ctr_z = (T)h->ctr[2]; p.omax2 = (T)h->omax2;
+    p.screen.ctr_x = (T)h->ctr[0]; p.screen.ctr_y = (T)h->ctr[1]; p.screen.ctr_z = (T)h->ctr[2]; p.screen.omax2 = (T)h->omax2;
 }
 
 }  // namespace

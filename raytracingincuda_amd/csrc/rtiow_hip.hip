@@ -125,8 +125,8 @@ int rtiow_create(int device, int precision, rtiow_handle* out) {
     if ((e = hipSetDevice(device)) != hipSuccess ||
         (e = acquire_stream(device, &h->stream)) != hipSuccess ||
         (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess ||
-        (e = hipEventCreate(&h->ev_a)) != hipSuccess || (e = hipEventCreate(&h->ev_b)) != hipSuccess) {
-        for (hipEvent_t ev : {h->ev0, h->ev1, h->ev_a, h->ev_b}) if (ev) (void)hipEventDestroy(ev);
+        (e = hipEventCreate(&h->ev_a)) != hipSuccess || (e = hipEventCreate(&h->ev_b)) != hipSuccess || (e = hipEventCreate(&h->ev_c)) != hipSuccess) {
+        for (hipEvent_t ev : {h->ev0, h->ev1, h->ev_a, h->ev_b, h->ev_c}) if (ev) (void)hipEventDestroy(ev);
         if (h->stream) release_stream(device, h->stream);
         delete h;
         return (int)e;
@@ -160,13 +160,14 @@ int rtiow_destroy(rtiow_handle h) {
     if (!h) return RTIOW_E_BADARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->geom_a, h->shade_tbl, h->geom_s, h->grid_blob, h->cost_rank, h->rng, h->jump, h->work_counter, h->mid,
+    void* bufs[] = {h->geom_a, h->shade_tbl, h->geom_s, h->grid_blob, h->cost_rank, h->rng, h->jump, h->work_counter, h->mid, h->slot_of, h->staged,
                     h->cost, h->order, h->sort_scratch, h->fb_external ? nullptr : h->fb};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_a) (void)hipEventDestroy(h->ev_a);
     if (h->ev_b) (void)hipEventDestroy(h->ev_b);
+    if (h->ev_c) (void)hipEventDestroy(h->ev_c);
     if (h->own_stream && h->stream) release_stream(h->device, h->stream);     // synchronised above
     delete h;
     return 0;
@@ -311,12 +312,15 @@ int render_wait(rtiow_handle_s* h, float* kernel_ms) {
     HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     if (kernel_ms) *kernel_ms = ms;
     h->stats.render_ms = ms;
-    h->stats.prepass_ms = 0; h->stats.main_ms = ms;
+    h->stats.prepass_ms = 0; h->stats.main_ms = ms; h->stats.place_ms = 0;
     if (h->stats.phases == 2) {
-        float a = 0, b = 0;
+        float a = 0, b = 0, c = 0;
         HIP_TRY(h, hipEventElapsedTime(&a, h->ev0, h->ev_a));
-        HIP_TRY(h, hipEventElapsedTime(&b, h->ev_b, h->ev1));
-        h->stats.prepass_ms = a; h->stats.main_ms = b;
+        if (h->stats.staged_stores) {
+            HIP_TRY(h, hipEventElapsedTime(&b, h->ev_b, h->ev_c));
+            HIP_TRY(h, hipEventElapsedTime(&c, h->ev_c, h->ev1));
+        } else HIP_TRY(h, hipEventElapsedTime(&b, h->ev_b, h->ev1));
+        h->stats.prepass_ms = a; h->stats.main_ms = b; h->stats.place_ms = c;
     }
     return 0;
 }

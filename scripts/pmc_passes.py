@@ -127,8 +127,10 @@ def derive(main, launch_ms=None):
     if insts:
         d["valu_wave_insts_per_launch"] = insts
         if main.get("SQ_THREAD_CYCLES_VALU") and main.get("SQ_ACTIVE_INST_VALU"):
-            # thread-cycles / (quad-cycles x 4 cycles x 64 lanes): the share of lanes that were enabled, cycle-weighted
-            d["active_lane_frac"] = main["SQ_THREAD_CYCLES_VALU"] / (main["SQ_ACTIVE_INST_VALU"] * 4.0 * 64.0)
+            # lanes enabled per vector instruction / 64.  Calibrated on a kernel that runs every instruction with all 64
+            # lanes (bin/valu_peak under the same counters: SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = 64.00,
+            # profiles/r03_lane_counter_calibration.json)
+            d["active_lane_frac"] = main["SQ_THREAD_CYCLES_VALU"] / (main["SQ_ACTIVE_INST_VALU"] * 64.0)
         if main.get("GRBM_GUI_ACTIVE"):
             cycles = main["GRBM_GUI_ACTIVE"] / 8.0                 # rocprofv3 sums the 8 XCDs
             d["launch_cycles_profiled"] = cycles
