@@ -24,10 +24,11 @@ __device__ __forceinline__ void rt_opaque(Rng& r) { asm volatile("" : "+v"(r.v0)
 #else
 #define RT_PROBE_DIRECT(T, smem, g, O, D, a, fd) ((void)0)
 #endif
-#ifdef RTIOW_PROBE_RUV         // shade_step: random_unit_vector a second time on a copy of the generator
-#define RT_PROBE_RUV(T, rs) do { Rng c_ = (rs); rt_opaque(c_); V3<T> r2 = random_unit_vector<T>(c_); RT_KEEP1(r2.x); RT_KEEP1(r2.y); RT_KEEP1(r2.z); RT_KEEP1(c_.v4); } while (0)
+#ifdef RTIOW_PROBE_RUV         // the rejection rounds of random_unit_vector a second time on a copy of the generator
+#define RT_PROBE_RUV(T, rs, rounds) do { Rng c_ = (rs); rt_opaque(c_); T x_, y_, z_, l_; const bool f_ = random_unit_vector_rounds<T>(c_, (rounds), x_, y_, z_, l_); \
+        RT_KEEP1(x_); RT_KEEP1(y_); RT_KEEP1(z_); RT_KEEP1(l_); RT_KEEP1((int)f_); RT_KEEP1(c_.v4); } while (0)
 #else
-#define RT_PROBE_RUV(T, rs) ((void)0)
+#define RT_PROBE_RUV(T, rs, rounds) ((void)0)
 #endif
 #ifdef RTIOW_PROBE_GEN         // persistent_body: the primary ray a second time
 #define RT_PROBE_GEN(T, p, i, j, rs) do { Rng c_ = (rs); rt_opaque(c_); V3<T> o2, d2; T u2; gen_primary((p), (i), (j), c_, o2, d2, u2); \
@@ -41,10 +42,10 @@ __device__ __forceinline__ void rt_opaque(Rng& r) { asm volatile("" : "+v"(r.v0)
 #else
 #define RT_PROBE_HIT(T, SRC, p, lds_geom, O, D) ((void)0)
 #endif
-#ifdef RTIOW_PROBE_SHADE       // persistent_body: the shade step a second time on a copy of the path state
-#define RT_PROBE_SHADE(T, p, lds_shade, st, closest, hit) do { PathState<T> s2 = (st); rt_opaque(s2.O); rt_opaque(s2.D); rt_opaque(s2.rs); V3<T> c2; \
-        const bool t2 = shade_step<T>((p), (lds_shade), s2, (closest), (hit), c2); RT_KEEP1(c2.x); RT_KEEP1(c2.y); RT_KEEP1(c2.z); RT_KEEP1(s2.O.x); \
-        RT_KEEP1(s2.D.x); RT_KEEP1(s2.D.y); RT_KEEP1(s2.D.z); RT_KEEP1(s2.rs.v4); RT_KEEP1(s2.atten.x); RT_KEEP1((int)t2); } while (0)
+#ifdef RTIOW_PROBE_SHADE       // persistent_body: the shade step up to the unit vector a second time on a copy of the path state
+#define RT_PROBE_SHADE(T, p, lds_shade, st, closest, hit) do { PathState<T> s2 = (st); rt_opaque(s2.O); rt_opaque(s2.D); rt_opaque(s2.rs); V3<T> c2; PendingScatter<T> q2; \
+        const int t2 = shade_begin<T>((p), (lds_shade), s2, (closest), (hit), c2, q2); RT_KEEP1(c2.x); RT_KEEP1(c2.y); RT_KEEP1(c2.z); RT_KEEP1(s2.O.x); \
+        RT_KEEP1(s2.D.x); RT_KEEP1(s2.D.y); RT_KEEP1(s2.D.z); RT_KEEP1(s2.rs.v4); RT_KEEP1(s2.atten.x); RT_KEEP1(q2.nrm.x); RT_KEEP1(q2.nrm.y); RT_KEEP1(q2.nrm.z); RT_KEEP1(q2.fuzz); RT_KEEP1(t2); } while (0)
 #else
 #define RT_PROBE_SHADE(T, p, lds_shade, st, closest, hit) ((void)0)
 #endif

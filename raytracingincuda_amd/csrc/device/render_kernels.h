@@ -66,11 +66,35 @@ render_kernel(const RenderParams<T> p) {
 // tile-major from the BOTTOM of the image up (ground and spheres first, cheap sky last) to
 // keep the drain tail short.  Per-pixel work and RNG streams are unchanged => same image.
 constexpr int POOL = 64;
+// Carry-over form of random_unit_vector (fp64 kernels): rejection rounds a wave runs per iteration before the lanes
+// still without a candidate carry their loop over into the next iteration (random_unit_vector_rounds,
+// PendingScatter).  Unbounded in the drain, where a lone chain's latency counts and no other lane waits for the rounds.
+// Measured on one box against the blocking loop (profiles/r03_ab_carry_over_unit_vector_rounds.jsonl): the main launch
+// issues 5-6 % fewer vector instructions in both precisions (a wave's loop is as long as its slowest lane's: 5.5 rounds
+// per iteration at 11 live lanes), fp64 -- whose round is six XORWOW steps -- renders 5 % faster, fp32 does not: the
+// restructured body issues 12 % more scalar instructions (exec-mask bookkeeping of the extra regions) and holds 5 more
+// VGPRs, every instruction costs a wave the same ~4.7 cycles of its own time whatever its kind, and small frames and
+// shards -- bound by the latency of a chain -- lose 6-10 %.  So: fp64 only.
+#ifndef RTIOW_RUV_ROUNDS_PER_ITERATION
+#define RTIOW_RUV_ROUNDS_PER_ITERATION 3
+#endif
 // Longest share of the brute-force sphere loop (trips of four spheres) for which the drain still splits it
 // among idle lanes instead of walking the grid (persistent_body).
 #ifndef RTIOW_COOP_MAX_TRIPS
 #define RTIOW_COOP_MAX_TRIPS 6
 #endif
+
+// Slot -> pixel of the tile-ordered hand-out (no cost order): 8 x 8 tiles from the bottom of the image up, 64 slots
+// per tile.  False for the padded slots of ragged tiles.
+template <class COLD>
+__device__ __forceinline__ bool tile_slot_pixel(const COLD& c, int slot, int& i, int& jl) {
+    const int tiles_x = (c.W + 7) >> 3, tiles_y = (c.local_rows + 7) >> 3;
+    const int t = slot >> 6, within = slot & 63;
+    const int ty = tiles_y - 1 - t / tiles_x, tx = t % tiles_x;
+    i = tx * 8 + (within & 7);
+    jl = ty * 8 + (within >> 3);
+    return i < c.W && jl < c.local_rows;
+}
 
 template <class T, int SRC, bool COUNT, bool SOLO = false>
 __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
@@ -85,7 +109,11 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
     st.acc = {0, 0, 0};
     st.sample = 0; st.depth = 0;
     unsigned int cost = 0;                       // segments of the lane's current pixel in this launch
+    constexpr bool CARRY = sizeof(T) == 8;       // see RTIOW_RUV_ROUNDS_PER_ITERATION
     bool alive = false, fresh = false;
+    bool pending = false;                        // the lane's path waits for its random_unit_vector (carry-over form)
+    PendingScatter<T> pend;
+    pend.nrm = {0, 0, 0}; pend.fuzz = 0;
     int i = 0, j = 0;
     size_t lp = 0;
     unsigned int nseg = 0;
@@ -160,14 +188,7 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
                         valid = px >= 0;
                         jl = valid ? px / c.W : 0;
                         i = valid ? px - jl * c.W : 0;
-                    } else {                                     // 8x8 tiles, bottom-up
-                        const int tiles_x = (c.W + 7) >> 3, tiles_y = (c.local_rows + 7) >> 3;
-                        const int t = slot >> 6, within = slot & 63;
-                        const int ty = tiles_y - 1 - t / tiles_x, tx = t % tiles_x;
-                        i = tx * 8 + (within & 7);
-                        jl = ty * 8 + (within >> 3);
-                        valid = i < c.W && jl < c.local_rows;    // padded slots of ragged tiles are skipped
-                    }
+                    } else valid = tile_slot_pixel(c, slot, i, jl);   // 8x8 tiles, bottom-up
                     if (valid) {
                         want = false;
                         j = global_row(jl, c.strip_rows, c.nranks, c.rank);
@@ -201,7 +222,7 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
         bool terminated = false;
         V3<T> col = {0, 0, 0};
         // hit_world for every lane that still traces (camera.h:84-88), then ONE shade site
-        const bool need_hit = alive && st.depth < p.B;
+        const bool need_hit = alive && !(CARRY && pending) && st.depth < p.B;
         T closest = __builtin_huge_val();
         int hit = -1;
         bool share_loops = (exhausted || (SOLO && solo) || 2 * p.lane_cap <= wave_lanes) && 2 * __builtin_popcountll(alive_mask) <= wave_lanes;
@@ -237,9 +258,36 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
         }
         REGION_BEGIN(shade);
         if (alive && need_hit) RT_PROBE_SHADE(T, p, lds_shade, st, closest, hit);
-        if (alive) {
-            if (need_hit) { ++cost; if (COUNT) ++nseg; }
-            terminated = need_hit ? shade_step<T>(p, lds_shade, st, closest, hit, col) : true;   // camera.h:127 at the depth limit
+        if (!CARRY) {
+            if (alive) {
+                if (need_hit) { ++cost; if (COUNT) ++nseg; }
+                terminated = need_hit ? shade_step<T>(p, lds_shade, st, closest, hit, col) : true;   // camera.h:127 at the depth limit
+            }
+        } else {
+            if (alive && !pending) {
+                if (need_hit) {
+                    ++cost; if (COUNT) ++nseg;
+                    const int r = shade_begin<T>(p, lds_shade, st, closest, hit, col, pend);
+                    terminated = r == SHADE_ENDED;
+                    pending = r == SHADE_NEEDS_UNIT_VECTOR;
+                } else terminated = true;                                            // camera.h:127 at the depth limit
+            }
+            // random_unit_vector for the lanes that scatter diffusely -- those of this iteration and those carried over
+            if (__builtin_amdgcn_ballot_w64(pending) != 0) {
+                T ux = 0, uy = 0, uz = 0, lensq = 1;
+                bool found = false;
+                const int rounds = share_loops ? 0x7fffffff : RTIOW_RUV_ROUNDS_PER_ITERATION;
+                if (pending) {
+                    RT_PROBE_RUV(T, st.rs, rounds);
+                    PATH_STAT(PS_RUV_CALL);
+                    found = random_unit_vector_rounds<T>(st.rs, rounds, ux, uy, uz, lensq);
+                }
+                if (found) {                                                         // the accepted candidate, normalised once (vec3.h:126)
+                    const T inv = inv_sqrt_accepted(lensq);
+                    terminated = shade_finish<T>(st, pend, V3<T>{inv * ux, inv * uy, inv * uz});
+                    pending = false;
+                }
+            }
         }
         REGION_END(shade, RG_SHADE);
         REGION_BEGIN(acc);
@@ -275,8 +323,13 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
 // The same body under two kernel names, so that profiles tell the launches of RTIOW_SCHED_SORTED
 // apart: the prepass (samples [0, SA) in tile order, ~1.4 ms of the headline frame) and the main
 // launch (everything else; also the only launch of RTIOW_SCHED_PERSISTENT).
+#ifdef RTIOW_MAIN_WAVES_PER_EU      // experiment builds only: ask the allocator to fit that many waves per SIMD (80 VGPRs for 6)
+#define RT_MAIN_OCCUPANCY __attribute__((amdgpu_waves_per_eu(RTIOW_MAIN_WAVES_PER_EU)))
+#else
+#define RT_MAIN_OCCUPANCY
+#endif
 template <class T, int SRC, bool COUNT>
-__global__ void __launch_bounds__(1024) render_persistent_kernel(const RenderParams<T> p) { persistent_body<T, SRC, COUNT>(p); }
+__global__ void __launch_bounds__(1024) RT_MAIN_OCCUPANCY render_persistent_kernel(const RenderParams<T> p) { persistent_body<T, SRC, COUNT>(p); }
 template <class T, int SRC, bool COUNT>
 __global__ void __launch_bounds__(1024) render_prepass_kernel(const RenderParams<T> p) { persistent_body<T, SRC, COUNT>(p); }
 // The main launch of a partly filled GPU (small frame, shard of a multi-GPU frame): the same body with the solo

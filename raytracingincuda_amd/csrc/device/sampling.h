@@ -27,6 +27,25 @@ template <class T> __device__ __forceinline__ V3<T> random_unit_vector(Rng& s) {
     return {inv * x, inv * y, inv * z};
 }
 
+// The same rejection loop, at most `rounds` rounds of it (carry-over form, persistent kernels): a lane that has not
+// found its candidate yet returns false with the generator advanced by the rounds it drew, and goes on in the wave's
+// next iteration.  A wave's loop is as long as its slowest lane's -- 5.5 rounds per iteration for the ~35 lanes that
+// scatter diffusely, at 11 live lanes on average -- while the candidates a lane draws, and their order, are its own:
+// cutting the loop and resuming it later changes nothing for the pixel.  Accepted: x, y, z, lensq hold the candidate.
+template <class T> __device__ __forceinline__ bool random_unit_vector_rounds(Rng& s, int rounds, T& x, T& y, T& z, T& lensq) {
+    for (int r = 0; r < rounds; ++r) {
+        PATH_STAT(PS_RUV_ROUND);
+        T u0, u1, u2;
+        Real<T>::uniform3(s, u0, u1, u2);
+        x = RT_FMA(u0, (T)2, (T)-1);
+        y = RT_FMA(u1, (T)2, (T)-1);
+        z = RT_FMA(u2, (T)2, (T)-1);
+        lensq = RT_FMA(z, z, RT_FMA(y, y, x * x));
+        if (Real<T>::ruv_eps < lensq && lensq <= (T)1) return true;
+    }
+    return false;
+}
+
 // One primary ray: camera.h:145-155 (+ :73-76, vec3.h:109-115).  Also returns the y
 // component of the PRIMARY ray's unit direction, all the sky term needs (camera.h:121).
 template <class T>

@@ -14,11 +14,20 @@ template <class T> struct PathState {
     Rng rs;
 };
 
-// Everything after hit_world in one trip of the loop at camera.h:84: sky on a miss
-// (camera.h:120-124), else hit record + scatter (camera.h:88-117).  Returns true when the
-// path ended; `col` is then its colour.
+// What a lane keeps while it waits for its random_unit_vector (carry-over form of the persistent kernels,
+// random_unit_vector_rounds): the normal and the fuzz -- negative for a lambertian, which has none.  A metal's unit
+// reflected direction waits in st.D (the incoming direction is spent once the hit record is complete).
+template <class T> struct PendingScatter { V3<T> nrm; T fuzz; };
+
+enum { SHADE_CONTINUES = 0, SHADE_ENDED = 1, SHADE_NEEDS_UNIT_VECTOR = 2 };
+
+// Everything after hit_world in one trip of the loop at camera.h:84, up to the material's random_unit_vector: sky
+// on a miss (camera.h:120-124: SHADE_ENDED, `col` is the path's colour), else hit record + scatter
+// (camera.h:88-117).  A dielectric is complete here (SHADE_CONTINUES: the next segment is in st); a lambertian or a
+// metal returns SHADE_NEEDS_UNIT_VECTOR with origin and attenuation already advanced -- attenuation is applied to a
+// path that continues (camera.h:110-115), and a metal that ends instead (material.h:58) ends black, whatever it holds.
 template <class T>
-__device__ __forceinline__ bool shade_step(const RenderParams<T>& p, const T* lds_shade, PathState<T>& st, T closest, int hit, V3<T>& col) {
+__device__ __forceinline__ int shade_begin(const RenderParams<T>& p, const T* lds_shade, PathState<T>& st, T closest, int hit, V3<T>& col, PendingScatter<T>& pend) {
     col = {0, 0, 0};
     const V3<T> O = st.O, D = st.D;
     if (hit < 0) {
@@ -28,7 +37,7 @@ __device__ __forceinline__ bool shade_step(const RenderParams<T>& p, const T* ld
         const T w1 = (T)(1.0 - a_sky), w2 = (T)a_sky;
         const V3<T> sky = {RT_FMA(w2, (T)0.5, w1), RT_FMA(w2, (T)0.7, w1), RT_FMA(w2, (T)1.0, w1)};
         col = {st.atten.x * sky.x, st.atten.y * sky.y, st.atten.z * sky.z};
-        return true;
+        return SHADE_ENDED;
     }
     // ------------ complete the hit record (hittable.h:59-63, :21-26)
     // one 12-word record per sphere; LDS copy when it fits (no global-load latency on the
@@ -50,12 +59,9 @@ __device__ __forceinline__ bool shade_step(const RenderParams<T>& p, const T* ld
     const bool front = dot3(D, outward) < (T)0;
     const V3<T> nrm = front ? outward : V3<T>{-outward.x, -outward.y, -outward.z};
     const int mtype = (int)rec[10];
-    V3<T> nd;
-    V3<T> att = {rec[4], rec[5], rec[6]};
-    bool ok = true;
     if (mtype == RTIOW_DIELECTRIC) {                                     // material.h:68-89
         PATH_STAT(PS_DIELECTRIC);
-        att = {1, 1, 1};
+        V3<T> nd;
         const T ri = front ? rec[9] : rec[8];
         const V3<T> ud = unit3(D);
         const T cos_theta = Real<T>::fmin(-dot3(ud, nrm), (T)1);
@@ -77,25 +83,50 @@ __device__ __forceinline__ bool shade_step(const RenderParams<T>& p, const T* ld
             const T k = -sqrt_wave_checked(Real<T>::fabs((T)1 - dot3(perp, perp)));
             nd = madd3(k, nrm, perp);
         }
-    } else {
-        RT_PROBE_RUV(T, st.rs);
-        const V3<T> ruv = random_unit_vector<T>(st.rs);
-        if (mtype == RTIOW_LAMBERTIAN) {                                 // material.h:38-49
-            nd = {nrm.x + ruv.x, nrm.y + ruv.y, nrm.z + ruv.z};
-            const T e = Real<T>::near_zero;
-            if (Real<T>::fabs(nd.x) < e && Real<T>::fabs(nd.y) < e && Real<T>::fabs(nd.z) < e) nd = nrm;
-        } else {                                                         // material.h:51-59
-            PATH_STAT(PS_METAL);
-            const V3<T> ur = unit3(reflect3(D, nrm));
-            nd = madd3(rec[7], ruv, ur);
-            ok = dot3(nd, nrm) > (T)0;
-        }
+        st.O = P; st.D = nd;                                             // camera.h:110-115 with attenuation (1,1,1): x * 1 is x, bit for bit
+        ++st.depth;
+        return SHADE_CONTINUES;
     }
-    if (!ok) return true;                                                // camera.h:117
-    st.atten = {st.atten.x * att.x, st.atten.y * att.y, st.atten.z * att.z};   // camera.h:110-115
-    st.O = P; st.D = nd;
+    st.atten = {st.atten.x * rec[4], st.atten.y * rec[5], st.atten.z * rec[6]};   // camera.h:110-115
+    st.O = P;
+    pend.nrm = nrm;
+    if (mtype == RTIOW_LAMBERTIAN) {
+        pend.fuzz = (T)-1;
+    } else {                                                             // material.h:51-59: unit_vector(reflect(...)) does not depend on the draws
+        PATH_STAT(PS_METAL);
+        pend.fuzz = rec[7];                                              // material.h:29-30: in [0, 1]
+        st.D = unit3(reflect3(D, nrm));
+    }
+    return SHADE_NEEDS_UNIT_VECTOR;
+}
+
+// The rest of lambertian_scatter / metal_scatter once the unit vector is there (material.h:38-59).  Returns true when
+// the path ended (a metal scattering below the surface: black, camera.h:117).
+template <class T>
+__device__ __forceinline__ bool shade_finish(PathState<T>& st, const PendingScatter<T>& pend, V3<T> ruv) {
+    const V3<T> nrm = pend.nrm;
+    V3<T> nd;
+    if (pend.fuzz < (T)0) {                                              // material.h:38-49
+        nd = {nrm.x + ruv.x, nrm.y + ruv.y, nrm.z + ruv.z};
+        const T e = Real<T>::near_zero;
+        if (Real<T>::fabs(nd.x) < e && Real<T>::fabs(nd.y) < e && Real<T>::fabs(nd.z) < e) nd = nrm;
+    } else {                                                             // material.h:51-59
+        nd = madd3(pend.fuzz, ruv, st.D);
+        if (!(dot3(nd, nrm) > (T)0)) return true;
+    }
+    st.D = nd;
     ++st.depth;
     return false;
+}
+
+// The whole step in one go (static schedule, one lane = one pixel: nothing to carry over).
+template <class T>
+__device__ __forceinline__ bool shade_step(const RenderParams<T>& p, const T* lds_shade, PathState<T>& st, T closest, int hit, V3<T>& col) {
+    PendingScatter<T> pend;
+    const int r = shade_begin<T>(p, lds_shade, st, closest, hit, col, pend);
+    if (r != SHADE_NEEDS_UNIT_VECTOR) return r == SHADE_ENDED;
+    RT_PROBE_RUV(T, st.rs, 0x7fffffff);
+    return shade_finish<T>(st, pend, random_unit_vector<T>(st.rs));
 }
 
 // One path segment (one trip of the loop at camera.h:84) done by the lane alone.

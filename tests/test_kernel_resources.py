@@ -61,7 +61,7 @@ def test_main_launch_register_budget(kernel_metadata):
     static = _find(meta, "render_kernel<float, 0, false>")
     assert static["sgpr_spill"] == 0 and static["vgpr"] <= 96, static
     f64 = _find(meta, "render_persistent_kernel<double, 0, false>")
-    assert f64["sgpr_spill"] <= 12 and f64["vgpr"] <= 128, f64      # four waves per SIMD
+    assert f64["sgpr_spill"] <= 16 and f64["vgpr"] <= 128, f64      # four waves per SIMD
     assert _find(meta, "render_solo_kernel<double, 0>")["vgpr"] <= 128
 
 
