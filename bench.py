@@ -214,9 +214,10 @@ def roofline_object(args, st, segments_main_rank0, main_ms, pmc, pmc_note, world
         main = pmc["counters"].get("main", {})
         d = pmc_passes.derive(main, launch_ms=mms)
         if d.get("valu_wave_insts_per_launch"):
-            # one FMA issue slot = 64 lanes x 2 flop; fp64 FMA slots are half as many per second (peak above)
-            achieved = d["valu_wave_insts_per_launch"] * 128.0 / (mms * 1e-3) / 1e12 * (1.0 if prec == 32 else 0.5)
-            frac = achieved / peak
+            # frac = share of the SIMD-32 issue slots filled (2 cycles per wave64 instruction, 1024 SIMDs, 2.4 GHz); achieved = that share of
+            # the peak, i.e. one FMA issue slot = 64 lanes x 2 flop (fp64 FMA slots are half as many per second: the fp64 peak above)
+            frac = d["valu_issue_frac"]
+            achieved = frac * peak
             issued = {"valu_wave_insts_per_launch": d["valu_wave_insts_per_launch"],
                       "valu_issue_frac": round(d["valu_issue_frac"], 4),
                       "simd_cycles_per_valu_inst_profiled": round(d["simd_cycles_per_valu_inst"], 3) if "simd_cycles_per_valu_inst" in d else None,

@@ -82,6 +82,10 @@ __device__ __forceinline__ void coop_solo(const RenderParams<double>&, const dou
 // sequential loop returns.  This cuts the latency of one segment from N sphere tests to
 // N/g, which is what bounds the kernel once only the long glass paths are left.
 template <class T> struct CoopSlot { T ox, oy, oz, a, dx, dy, dz, pad; };
+// Slots a wave needs: the drain shares loops only while at most half of the wave's lanes carry a ray (persistent_body:
+// 2 * popcount(alive) <= wave_lanes), so 32.  (64 until round 3: the 4 KB per workgroup were what kept the
+// 487-sphere scene at four workgroups per CU -- 35.1 KB of LDS each -- instead of five.)
+constexpr int COOP_SLOTS = 32;
 
 // the value lane l holds, as a wave-uniform scalar
 __device__ __forceinline__ float lane_value(float v, int l) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); }

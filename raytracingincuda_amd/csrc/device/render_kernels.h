@@ -102,7 +102,7 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
     // per-wave scratch for hit_world_coop, behind the staged tables
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const T* lds_shade = reinterpret_cast<const T*>(smem_raw + p.shade_offset);
-    CoopSlot<T>* coop_slots = reinterpret_cast<CoopSlot<T>*>(smem_raw + p.coop_offset) + (threadIdx.x >> 6) * 64;
+    CoopSlot<T>* coop_slots = reinterpret_cast<CoopSlot<T>*>(smem_raw + p.coop_offset) + (threadIdx.x >> 6) * COOP_SLOTS;
     const int S = p.s_end;                       // this launch renders samples [cold.s_begin, p.s_end)
 
     PathState<T> st;
