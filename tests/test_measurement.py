@@ -101,6 +101,19 @@ def test_roofline_frac_is_executed_work_or_null():
     assert bench.roofline_object(_args(), st, 468_000_000, main_ms, pmc, "test", 2)["frac"] is None
 
 
+def test_failing_live_passes_do_not_take_the_bench_line_down(monkeypatch):
+    """No rocprofv3, no permission to profile, a pass that dies: bench.py notes why and goes on (frac null or the committed record)."""
+    import bench
+    import pmc_passes
+    def boom(*a, **k):
+        raise RuntimeError("rocprofv3 not found")
+    monkeypatch.setattr(pmc_passes, "collect", boom)
+    rec, note = bench.pmc_live(_args())
+    assert rec is None and "live passes failed" in note and "rocprofv3 not found" in note
+    monkeypatch.setenv("ROCPROFILER_REGISTER_FORCE_LOAD", "1")
+    assert bench.under_a_profiler()                     # bench.py below rocprofv3 itself: no nested passes
+
+
 def test_committed_records_name_their_build(native):
     """profiles/pmc_records.json: every record carries a build id; those of the current tree (if any) make
     `bench.py --pmc committed` print a figure, the others make it print null -- which this test reports, not fails."""
