@@ -211,6 +211,9 @@ def test_per_launch_timing_and_segment_counts(rt):
         st = r.stats()
         assert st["phases"] == 2 and st["prepass_samples"] == 3
         assert 0 < st["prepass_ms"] and 0 < st["main_ms"] and st["prepass_ms"] + st["main_ms"] <= ms * 1.001
+        # finished pixels are staged in slot order and place_pixels_kernel writes the image (its own event pair, inside render_ms)
+        assert st["staged_stores"] == 1 and 0 < st["place_ms"] < 0.5 and st["prepass_ms"] + st["main_ms"] + st["place_ms"] <= ms * 1.001
+        assert st["scene_prepare_ms"] > 0            # screening table + grid plan of this scene, host time before the first start event
         assert st["segments_prepass"] + st["segments_main"] == total
         assert 0.02 < st["segments_prepass"] / total < 0.10            # 3 of 64 samples
         r.set_schedule(rt.SCHED_PERSISTENT)
@@ -218,7 +221,7 @@ def test_per_launch_timing_and_segment_counts(rt):
         assert r.count_segments(0) == total
         st = r.stats()
         assert st["phases"] == 1 and st["prepass_samples"] == 0 and st["segments_prepass"] == 0 and st["segments_main"] == total
-        assert abs(st["main_ms"] - ms) < 1e-6 and st["prepass_ms"] == 0
+        assert abs(st["main_ms"] - ms) < 1e-6 and st["prepass_ms"] == 0 and st["staged_stores"] == 0 and st["place_ms"] == 0
 
 
 def test_segment_count_matches_oracle(rt, oracle):
