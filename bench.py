@@ -224,7 +224,7 @@ def roofline_object(args, st, segments_main_rank0, main_ms, pmc, pmc_note, world
                       "valu_issue_frac_at_profiled_clock": round(d["valu_issue_frac_at_profiled_clock"], 4) if "valu_issue_frac_at_profiled_clock" in d else None,
                       "active_lane_frac": round(d["active_lane_frac"], 4) if "active_lane_frac" in d else None,
                       "salu_insts_per_launch": main.get("SQ_INSTS_SALU"),
-                      "wave_cycles_split": {k: main.get(k) for k in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU") if main.get(k)},
+                      "wave_cycles_split": {k: main.get(k) for k in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA") if main.get(k)},   # quad-cycles of resident waves: waiting (s_waitcnt), waiting for an issue slot, issuing vector / scalar instructions
                       "prepass_valu_wave_insts": pmc["counters"].get("prepass", {}).get("SQ_INSTS_VALU")}
         t = pmc.get("traffic_main")
         if t:

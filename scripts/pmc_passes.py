@@ -5,7 +5,7 @@ The render path is bound by vector-ALU issue, so the roofline 
 fraction of the SIMDs' issue slots the main launch fills -- SQ_INSTS_VALU against the launch time -- and HBM
 traffic is evidence that the path is nowhere near the memory roof.  Both come from hardware counters:
 
-  pass "sq"     SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES
+  pass "sq"     SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES
                 SQ_WAIT_INST_ANY SQ_WAIT_ANY (the 8 SQ slots of gfx950) + GRBM_GUI_ACTIVE (its own block)
   pass "fetch"  FETCH_SIZE      } separate passes, as MI355X_MICROARCH.md (HBM, rocprofv3 PMC slots) prescribes:
   pass "write"  WRITE_SIZE      } the two do not fit the TCC's 4 slots together
@@ -33,7 +33,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 PASSES = {
-    "sq": ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
+    "sq": ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_SCA", "SQ_WAVE_CYCLES",
            "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"],
     "fetch": ["FETCH_SIZE"],
     "write": ["WRITE_SIZE"],
