@@ -42,10 +42,10 @@ __device__ __forceinline__ void rt_opaque(Rng& r) { asm volatile("" : "+v"(r.v0)
 #else
 #define RT_PROBE_HIT(T, SRC, p, lds_geom, O, D) ((void)0)
 #endif
-#ifdef RTIOW_PROBE_SHADE       // persistent_body: the shade step up to the unit vector a second time on a copy of the path state
-#define RT_PROBE_SHADE(T, p, lds_shade, st, closest, hit) do { PathState<T> s2 = (st); rt_opaque(s2.O); rt_opaque(s2.D); rt_opaque(s2.rs); V3<T> c2; PendingScatter<T> q2; \
-        const int t2 = shade_begin<T>((p), (lds_shade), s2, (closest), (hit), c2, q2); RT_KEEP1(c2.x); RT_KEEP1(c2.y); RT_KEEP1(c2.z); RT_KEEP1(s2.O.x); \
-        RT_KEEP1(s2.D.x); RT_KEEP1(s2.D.y); RT_KEEP1(s2.D.z); RT_KEEP1(s2.rs.v4); RT_KEEP1(s2.atten.x); RT_KEEP1(q2.nrm.x); RT_KEEP1(q2.nrm.y); RT_KEEP1(q2.nrm.z); RT_KEEP1(q2.fuzz); RT_KEEP1(t2); } while (0)
+#ifdef RTIOW_PROBE_SHADE       // persistent_body: the shade step (with its random_unit_vector) a second time on a copy of the path state
+#define RT_PROBE_SHADE(T, p, lds_shade, st, closest, hit) do { PathState<T> s2 = (st); rt_opaque(s2.O); rt_opaque(s2.D); rt_opaque(s2.rs); V3<T> c2; bool r2_; \
+        const bool t2 = shade_step<T, false>((p), (lds_shade), s2, (closest), (hit), c2, 0, r2_); RT_KEEP1(c2.x); RT_KEEP1(c2.y); RT_KEEP1(c2.z); RT_KEEP1(s2.O.x); \
+        RT_KEEP1(s2.D.x); RT_KEEP1(s2.D.y); RT_KEEP1(s2.D.z); RT_KEEP1(s2.rs.v4); RT_KEEP1(s2.atten.x); RT_KEEP1((int)t2); } while (0)
 #else
 #define RT_PROBE_SHADE(T, p, lds_shade, st, closest, hit) ((void)0)
 #endif

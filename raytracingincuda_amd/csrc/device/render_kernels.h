@@ -66,15 +66,14 @@ render_kernel(const RenderParams<T> p) {
 // tile-major from the BOTTOM of the image up (ground and spheres first, cheap sky last) to
 // keep the drain tail short.  Per-pixel work and RNG streams are unchanged => same image.
 constexpr int POOL = 64;
-// Carry-over form of random_unit_vector (fp64 kernels): rejection rounds a wave runs per iteration before the lanes
-// still without a candidate carry their loop over into the next iteration (random_unit_vector_rounds,
-// PendingScatter).  Unbounded in the drain, where a lone chain's latency counts and no other lane waits for the rounds.
-// Measured on one box against the blocking loop (profiles/r03_ab_carry_over_unit_vector_rounds.jsonl): the main launch
-// issues 5-6 % fewer vector instructions in both precisions (a wave's loop is as long as its slowest lane's: 5.5 rounds
-// per iteration at 11 live lanes), fp64 -- whose round is six XORWOW steps -- renders 5 % faster, fp32 does not: the
-// restructured body issues 12 % more scalar instructions (exec-mask bookkeeping of the extra regions) and holds 5 more
-// VGPRs, every instruction costs a wave the same ~4.7 cycles of its own time whatever its kind, and small frames and
-// shards -- bound by the latency of a chain -- lose 6-10 %.  So: fp64 only.
+// Bounded rejection loop of random_unit_vector (shade_step<T, true>, fp64 persistent kernels): rounds a wave runs per
+// iteration before the lanes still without a candidate resume in the next one.  Unbounded in the drain, where a lone
+// chain's latency counts and no other lane waits for the rounds.  Measured on one box against the blocking loop
+// (profiles/r03_ab_carry_over_unit_vector_rounds.jsonl, r03_ab_retry_unit_vector_rounds.jsonl): the main launch issues
+// 5-6 % fewer vector instructions in both precisions and fp64 -- whose round is six XORWOW steps -- renders 5 % faster;
+// fp32 does not: a lane that waits costs its wave a whole iteration's worth of the work every iteration does whatever
+// the lane count (hit_world's set-up and direct list, the shade prologue: half of an iteration), which is what the
+// saved rounds were worth, and small frames and shards, bound by the latency of one chain, lose 2-4 %.  So: fp64 only.
 #ifndef RTIOW_RUV_ROUNDS_PER_ITERATION
 #define RTIOW_RUV_ROUNDS_PER_ITERATION 3
 #endif
@@ -109,11 +108,17 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
     st.acc = {0, 0, 0};
     st.sample = 0; st.depth = 0;
     unsigned int cost = 0;                       // segments of the lane's current pixel in this launch
-    constexpr bool CARRY = sizeof(T) == 8;       // see RTIOW_RUV_ROUNDS_PER_ITERATION
+#ifndef RTIOW_RUV_BOUNDED_F32
+#define RTIOW_RUV_BOUNDED_F32 0
+#endif
+#ifndef RTIOW_RUV_BOUNDED_F64
+#define RTIOW_RUV_BOUNDED_F64 1
+#endif
+    constexpr bool RETRY = sizeof(T) == 8 ? RTIOW_RUV_BOUNDED_F64 != 0 : RTIOW_RUV_BOUNDED_F32 != 0;   // see RTIOW_RUV_ROUNDS_PER_ITERATION
+    bool retry = false;                          // RETRY: the lane's rejection loop goes on in this iteration (closest, hit kept)
+    T closest = __builtin_huge_val();
+    int hit = -1;
     bool alive = false, fresh = false;
-    bool pending = false;                        // the lane's path waits for its random_unit_vector (carry-over form)
-    PendingScatter<T> pend;
-    pend.nrm = {0, 0, 0}; pend.fuzz = 0;
     int i = 0, j = 0;
     size_t lp = 0;
     unsigned int nseg = 0;
@@ -222,9 +227,8 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
         bool terminated = false;
         V3<T> col = {0, 0, 0};
         // hit_world for every lane that still traces (camera.h:84-88), then ONE shade site
-        const bool need_hit = alive && !(CARRY && pending) && st.depth < p.B;
-        T closest = __builtin_huge_val();
-        int hit = -1;
+        const bool need_hit = alive && !(RETRY && retry) && st.depth < p.B;
+        if (!(RETRY && retry)) { closest = __builtin_huge_val(); hit = -1; }
         bool share_loops = (exhausted || (SOLO && solo) || 2 * p.lane_cap <= wave_lanes) && 2 * __builtin_popcountll(alive_mask) <= wave_lanes;
         const unsigned long long hit_mask = __builtin_amdgcn_ballot_w64(need_hit);
         if (share_loops && p.use_grid && hit_mask != 0) {
@@ -258,36 +262,11 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
         }
         REGION_BEGIN(shade);
         if (alive && need_hit) RT_PROBE_SHADE(T, p, lds_shade, st, closest, hit);
-        if (!CARRY) {
-            if (alive) {
-                if (need_hit) { ++cost; if (COUNT) ++nseg; }
-                terminated = need_hit ? shade_step<T>(p, lds_shade, st, closest, hit, col) : true;   // camera.h:127 at the depth limit
-            }
-        } else {
-            if (alive && !pending) {
-                if (need_hit) {
-                    ++cost; if (COUNT) ++nseg;
-                    const int r = shade_begin<T>(p, lds_shade, st, closest, hit, col, pend);
-                    terminated = r == SHADE_ENDED;
-                    pending = r == SHADE_NEEDS_UNIT_VECTOR;
-                } else terminated = true;                                            // camera.h:127 at the depth limit
-            }
-            // random_unit_vector for the lanes that scatter diffusely -- those of this iteration and those carried over
-            if (__builtin_amdgcn_ballot_w64(pending) != 0) {
-                T ux = 0, uy = 0, uz = 0, lensq = 1;
-                bool found = false;
-                const int rounds = share_loops ? 0x7fffffff : RTIOW_RUV_ROUNDS_PER_ITERATION;
-                if (pending) {
-                    RT_PROBE_RUV(T, st.rs, rounds);
-                    PATH_STAT(PS_RUV_CALL);
-                    found = random_unit_vector_rounds<T>(st.rs, rounds, ux, uy, uz, lensq);
-                }
-                if (found) {                                                         // the accepted candidate, normalised once (vec3.h:126)
-                    const T inv = inv_sqrt_accepted(lensq);
-                    terminated = shade_finish<T>(st, pend, V3<T>{inv * ux, inv * uy, inv * uz});
-                    pending = false;
-                }
-            }
+        if (alive) {
+            if (need_hit) { ++cost; if (COUNT) ++nseg; }
+            if (need_hit || (RETRY && retry))
+                terminated = shade_step<T, RETRY>(p, lds_shade, st, closest, hit, col, share_loops ? 0x7fffffff : RTIOW_RUV_ROUNDS_PER_ITERATION, retry);
+            else terminated = true;                                                  // camera.h:127 at the depth limit
         }
         REGION_END(shade, RG_SHADE);
         REGION_BEGIN(acc);

@@ -27,11 +27,9 @@ template <class T> __device__ __forceinline__ V3<T> random_unit_vector(Rng& s) {
     return {inv * x, inv * y, inv * z};
 }
 
-// The same rejection loop, at most `rounds` rounds of it (carry-over form, persistent kernels): a lane that has not
-// found its candidate yet returns false with the generator advanced by the rounds it drew, and goes on in the wave's
-// next iteration.  A wave's loop is as long as its slowest lane's -- 5.5 rounds per iteration for the ~35 lanes that
-// scatter diffusely, at 11 live lanes on average -- while the candidates a lane draws, and their order, are its own:
-// cutting the loop and resuming it later changes nothing for the pixel.  Accepted: x, y, z, lensq hold the candidate.
+// The same rejection loop, at most `rounds` rounds of it (shade_step<T, true>): a lane that has not found its candidate
+// yet returns false with the generator advanced by the rounds it drew, and goes on in the wave's next iteration.
+// Accepted: x, y, z, lensq hold the candidate (the caller normalises it once, vec3.h:126).
 template <class T> __device__ __forceinline__ bool random_unit_vector_rounds(Rng& s, int rounds, T& x, T& y, T& z, T& lensq) {
     for (int r = 0; r < rounds; ++r) {
         PATH_STAT(PS_RUV_ROUND);
