@@ -55,7 +55,8 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     const int threads = bx * by;
     // A scene whose tables do not fit the CU's LDS next to the drain scratch (several thousand
     // spheres) is read through the scalar cache instead of failing: same image, exact loop.
-    const size_t coop_scratch = persistent ? (size_t)((threads + 63) / 64) * COOP_SLOTS * sizeof(CoopSlot<T>) : 0;
+    size_t coop_scratch = persistent ? (size_t)((threads + 63) / 64) * COOP_SLOTS * sizeof(CoopSlot<T>) : 0;
+    if (RTIOW_POOLED && persistent && coop_scratch < sizeof(PoolArea<T>)) coop_scratch = sizeof(PoolArea<T>);   // the pooled loop's area lies where the drain's slots lie
     bool lds_source = h->scene_source != RTIOW_SCENE_SCALAR;
     int effective_source = h->scene_source;
     const bool screened = h->scene_source == RTIOW_SCENE_LDS || h->scene_source == RTIOW_SCENE_GRID;
@@ -77,7 +78,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     if (p.use_screen) lds += sizeof(float) * 4 * (size_t)h->n_padded;
     p.cold.timeline = nullptr;                                    // set below, once the grid is known
     // shade records ride along in LDS while a workgroup's share stays within 1/5 of the CU's LDS
-    const size_t coop_bytes = persistent ? (size_t)((threads + 63) / 64) * COOP_SLOTS * sizeof(CoopSlot<T>) : 0;
+    const size_t coop_bytes = coop_scratch;
     const size_t shade_bytes = (sizeof(T) * 12 * (size_t)h->n + 15) / 16 * 16;
     p.shade_offset = (int)lds;
     // ... and a wave's share stays under ~6.5 KB, so that LDS never caps occupancy below 6 waves/SIMD

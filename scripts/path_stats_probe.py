@@ -7,7 +7,7 @@ import raytracingincuda_amd as rt
 from raytracingincuda_amd import api
 
 orig = api.lib_paths
-api.lib_paths = lambda: dict(orig(), hip=os.path.join(os.path.dirname(orig()["host"]), "librtiow_hip_stats.so"))
+api.lib_paths = lambda: dict(orig(), hip=os.environ.get("RTIOW_STATS_LIBRARY") or os.path.join(os.path.dirname(orig()["host"]), "librtiow_hip_stats.so"))
 a = sys.argv[1:]
 scene = int(a[0]) if a else 3
 W, H, S, B = (int(x) for x in a[1:5]) if len(a) >= 5 else (1920, 1080, 100, 50)
