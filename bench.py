@@ -56,6 +56,16 @@ import numpy as np  # noqa: E402
 VALU_FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz = one wave64 FMA per 2 cycles per SIMD
 VALU_FP64_PEAK_TFLOPS = 78.6      # v_fma_f64: half that rate (one wave64 instruction per 4 cycles)
 HBM_PEAK_GBS = 8000.0
+# What the part gives a stream of plain (un-packed) independent FMAs, measured with bin/valu_peak (profiles/r01_valu_peak.json): v_fma_f32 80.85 TFLOP/s
+# at 4 waves per SIMD, 84.65 at 8 (v_pk_fma_f32: 125-128); v_fma_f64 61.57 at 4 waves.  The render kernels run 5 (fp32) / 4 (fp64) waves per SIMD.
+PRACTICAL_FMA_TFLOPS = {32: 82.0, 64: 61.57}
+# Share of the fp64 main kernel's vector instructions that issue at the double-precision rate (v_*_f64: one wave64 instruction per 4 cycles; the rest --
+# generator steps, integer and fp32 grid walk, moves -- per 2), from the kernel's static ISA; tests/test_kernel_resources.py keeps it within +-0.04 of the compiler's.
+FP64_KERNEL_DP_SHARE = 0.69
+# Configurations rendered after the headline's timed region, from the same loaded library, so that the round's claims about them are on the
+# driver's clock too (N = 1 only): name -> (scene, W, H, spp, bounces, precision)
+EXTRA_CONFIGS = [("fp64_headline", (3, 1920, 1080, 100, 50, 64)), ("scene1_487_spheres_1080p", (1, 1920, 1080, 100, 50, 32)),
+                 ("baseline_config2_scene1_320x192_10spp_25b", (1, 320, 192, 10, 25, 32))]
 PMC_RECORDS = os.path.join(ROOT, "profiles", "pmc_records.json")
 
 
@@ -80,6 +90,7 @@ def parse():
                     help="where roofline.frac's counters come from: rocprofv3 --pmc passes run now (live), the committed record if it matches "
                          "the loaded build (committed), neither (off); auto = live at N = 1, falling back to committed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the extra_configs object (fp64 headline, 487-sphere scene, BASELINE config [1]; N = 1 only)")
     ap.add_argument("--no-scaling-probe", action="store_true",
                     help="skip the 1-pixel lone-ray probe (it launches the main kernel by the same name: keeps rocprofv3 --stats averages clean)")
     return ap.parse_args()
@@ -187,6 +198,63 @@ def lone_ray_trip_us(rt, device_index, prec, scene, args):
     return (best * 1e3 / segs if segs else None), segs
 
 
+def issue_fraction(valu_insts, launch_ms, precision, cus=256, clock_mhz=2400):
+    """(frac, cycles_per_inst): share of the SIMD-32 issue cycles the launch's vector instructions take.  fp32: 2 cycles per wave64 instruction.
+    fp64: the kernel's double-precision instructions (FP64_KERNEL_DP_SHARE of them) take 4, the others 2.  The device's compute units and
+    nominal clock come from the library (rtiow_stats.num_cus / clock_mhz = hipDeviceProp_t), not from a constant."""
+    cpi = 2.0 if precision == 32 else 2.0 * (1.0 - FP64_KERNEL_DP_SHARE) + 4.0 * FP64_KERNEL_DP_SHARE
+    return cpi * valu_insts / (cus * 4 * clock_mhz * 1e6 * launch_ms * 1e-3), cpi
+
+
+def device_of(st):
+    """Compute units and nominal clock of the device the handle runs on; MI355X figures when an older library does not report them."""
+    return {"cus": int(st.get("num_cus") or 256), "clock_mhz": int(st.get("clock_mhz") or 2400)}
+
+
+def run_extra_configs(rt, device_index, args, extra_pmc):
+    """fp64 headline, the 487-sphere scene at 1080p and BASELINE config [1], each rendered a few times by the library this bench has loaded
+    (after the headline's timed region).  `frac` / `active_lane_frac` from this run's own sq pass (extra_pmc) or the committed record of THIS build."""
+    import pmc_passes
+    out = []
+    for name, (scene_id, W, H, S, B, prec) in EXTRA_CONFIGS:
+        with rt.Renderer(device_index, prec) as r:
+            r.set_camera(rt.camera(prec, W, H, S, B))
+            r.set_scene(rt.build_scene(scene_id, prec))
+            r.set_scene_source(getattr(rt, SOURCES[args.scene_source]))
+            r.set_schedule(getattr(rt, SCHEDULES[args.schedule]))
+            r.init_rng(1227)
+            for _ in range(2):
+                r.render(0)
+            r.synchronize()
+            steps = 8 if W * H >= 1000000 else 20
+            main_ms = []
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                r.render(0, sync=True)
+                main_ms.append(r.stats()["main_ms"])
+            r.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            st = r.stats()
+        rec = extra_pmc.get(name)
+        note = "this run's rocprofv3 --pmc sq pass" if rec else None
+        if rec is None:
+            key = pmc_passes.config_key(scene_id, W, H, S, B, prec, args.schedule, args.scene_source)
+            rec = pmc_passes.load_record(PMC_RECORDS, key, rt.build_id())
+            note = "committed record of this build" if rec else None
+        frac = lanes = None
+        if rec and rec.get("build_id") == rt.build_id():
+            main = rec["counters"].get("main", {})
+            if main.get("SQ_INSTS_VALU"):
+                frac = round(issue_fraction(main["SQ_INSTS_VALU"], float(np.mean(main_ms)), prec, **device_of(st))[0], 4)
+            d = pmc_passes.derive(main)
+            lanes = round(d["active_lane_frac"], 4) if "active_lane_frac" in d else None
+        out.append({"name": name, "workload": "scene %d (%d spheres), %dx%d, %d spp, %d bounces, fp%d" % (scene_id, st["num_spheres"], W, H, S, B, prec),
+                    "steps": steps, "ms_per_step": round(ms, 4), "value": round(float(W) * H * S / (ms * 1e-3) / 1e6, 3), "unit": "Mrays/s",
+                    "main_launch_ms": round(float(np.mean(main_ms)), 4), "prepass_ms": round(float(st["prepass_ms"]), 4),
+                    "frac": frac, "active_lane_frac": lanes, "counters_from": note})
+    return out
+
+
 SOURCES = {"grid": "SCENE_GRID", "lds": "SCENE_LDS", "scalar": "SCENE_SCALAR", "lds_exact": "SCENE_LDS_EXACT"}
 SCHEDULES = {"sorted": "SCHED_SORTED", "persistent": "SCHED_PERSISTENT", "static": "SCHED_STATIC"}
 
@@ -216,10 +284,14 @@ def roofline_object(args, st, segments_main_rank0, main_ms, pmc, pmc_note, world
         if d.get("valu_wave_insts_per_launch"):
             # frac = share of the SIMD-32 issue slots filled (2 cycles per wave64 instruction, 1024 SIMDs, 2.4 GHz); achieved = that share of
             # the peak, i.e. one FMA issue slot = 64 lanes x 2 flop (fp64 FMA slots are half as many per second: the fp64 peak above)
-            frac = d["valu_issue_frac"]
+            dev = device_of(st)
+            frac, cycles_per_inst = issue_fraction(d["valu_wave_insts_per_launch"], mms, prec, **dev)
+            # the peaks are MI355X's (256 CUs at 2.4 GHz): on any other part the fraction still holds, the TFLOP/s figures are scaled with it
+            peak = peak * dev["cus"] * dev["clock_mhz"] / (256.0 * 2400.0)
             achieved = frac * peak
             issued = {"valu_wave_insts_per_launch": d["valu_wave_insts_per_launch"],
-                      "valu_issue_frac": round(d["valu_issue_frac"], 4),
+                      "valu_issue_frac": round(d["valu_issue_frac"], 4),    # every instruction at 2 cycles (the fp32 figure; a lower bound in fp64)
+                      "cycles_per_inst_charged": round(cycles_per_inst, 3),
                       "simd_cycles_per_valu_inst_profiled": round(d["simd_cycles_per_valu_inst"], 3) if "simd_cycles_per_valu_inst" in d else None,
                       "valu_issue_frac_at_profiled_clock": round(d["valu_issue_frac_at_profiled_clock"], 4) if "valu_issue_frac_at_profiled_clock" in d else None,
                       "active_lane_frac": round(d["active_lane_frac"], 4) if "active_lane_frac" in d else None,
@@ -232,9 +304,16 @@ def roofline_object(args, st, segments_main_rank0, main_ms, pmc, pmc_note, world
     kernel = {"static": "render_kernel", "persistent": "render_persistent_kernel", "sorted": "render_solo_kernel" if st["solo_waves"] else "render_persistent_kernel"}[args.schedule]
     return {"bound": "valu", "achieved": round(achieved, 3) if achieved is not None else None, "peak": peak, "unit": "TFLOP/s",
             "frac": round(frac, 4) if frac is not None else None, "traffic": traffic,
-            "achieved_is": "EXECUTED vector issue: SQ_INSTS_VALU wave-instructions of the main launch x 64 lanes x 2 flop (one FMA slot each) / launch time; "
-                           "frac = share of the SIMD-32 issue slots filled (a wave64 VALU instruction takes 2 cycles; fp64: 4). null: no counters for THIS build",
+            "achieved_is": "EXECUTED vector issue: frac = SIMD-32 issue cycles of the main launch's SQ_INSTS_VALU wave-instructions / (1024 SIMDs x 2.4 GHz x launch time), "
+                           "a wave64 instruction charged 2 cycles" + ("" if prec == 32 else "; in this fp64 kernel %.0f %% of them are double-precision instructions charged 4 "
+                           "(static ISA share, tests/test_kernel_resources.py): %.2f cycles per instruction" % (100 * FP64_KERNEL_DP_SHARE, 2 + 2 * FP64_KERNEL_DP_SHARE)) +
+                           "; achieved = frac x peak (the FMA slots of this precision: 64 lanes x 2 flop per 2 (fp32) / 4 (fp64) cycles per SIMD). null: no counters for THIS build",
+            "practical_peak": {"value": PRACTICAL_FMA_TFLOPS[prec], "unit": "TFLOP/s",
+                               "what": "measured ceiling of a stream of plain independent %s at %d waves per SIMD (bin/valu_peak, profiles/r01_valu_peak.json): what the "
+                                       "part gives un-packed vector code; v_pk_fma_f32 reaches 125-128" % (("v_fma_f32", 5) if prec == 32 else ("v_fma_f64", 4)),
+                               "frac_of_practical": round(achieved / PRACTICAL_FMA_TFLOPS[prec], 4) if achieved is not None else None},
             "counters_from": pmc_note, "build_id": pmc.get("build_id") if pmc else None, "issued": issued,
+            "device": device_of(st),    # what frac is rated against: 4 SIMDs per compute unit at the nominal clock, both from hipDeviceProp_t through the library
             "algorithmic_TFLOPs": round(algorithmic, 3), "algorithmic_frac": round(algorithmic / peak, 4),
             "algorithmic_is": "the reference's own sphere loop served per second: 23 flop x every sphere x every segment + 120 per segment + 60 per ray "
                               "(SURVEY.md 8d); the grid walk finds the same hits testing a few spheres per segment, so this is comparable work, not executed work",
@@ -291,6 +370,8 @@ def emit(json_fd, args, ctx):
         "gather_ms": round(ctx["gather_ms"], 4) if ctx["gather_ms"] is not None else None,
         "gather_transport": ctx.get("gather_transport"),
         "gather_bytes_total": int(W) * H * 3 * (4 if prec == 32 else 8) if world > 1 or ctx["backend"] else 0}
+    if ctx.get("extra_configs") is not None:
+        line["extra_configs"] = ctx["extra_configs"]
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
         line["cpu_baseline"]["config1"] = cpu_baseline_config1()
@@ -355,7 +436,7 @@ def run_group(args, json_fd):
     g.close()
 
 
-def run_ranks(args, json_fd, world, rank, local_rank, distributed, pmc, pmc_note):
+def run_ranks(args, json_fd, world, rank, local_rank, distributed, pmc, pmc_note, extra_pmc=None):
     """N = 1, or one process per GPU under torch.distributed.run."""
     import torch
     import torch.distributed as dist
@@ -462,8 +543,11 @@ def run_ranks(args, json_fd, world, rank, local_rank, distributed, pmc, pmc_note
         gather_ms_max, floor_ms, chain_max = None, floor_local, chain_main
         kernel_ms_per_rank, gather_ms_per_rank = [round(float(np.mean(kernel_ms)), 4)], None
 
+    extras = None
+    if world == 1 and not distributed and not args.no_extra_configs:
+        extras = run_extra_configs(rt, device_index, args, extra_pmc or {})       # after the timed region, same library
     if rank == 0:
-        ctx = {"world": world, "elapsed": elapsed, "kernel_ms": kernel_ms, "main_ms": main_ms, "stats0": r.stats(), "segments0": segments,
+        ctx = {"extra_configs": extras, "world": world, "elapsed": elapsed, "kernel_ms": kernel_ms, "main_ms": main_ms, "stats0": r.stats(), "segments0": segments,
                "segments_main0": segments_main0, "segments_total": segments_total, "kernel_mean_max": kernel_mean_max,
                "kernel_ms_per_rank": kernel_ms_per_rank, "gather_ms_per_rank": gather_ms_per_rank, "gather_ms": gather_ms_max,
                "gather_transport": ("torch.distributed gather, backend %s" % backend) if distributed else None,
@@ -500,13 +584,21 @@ def main():
     if args.gpus > 1 and not distributed:
         return run_group(args, json_fd)                 # no launcher: the in-library group drives the N GPUs from this process
     # counter passes of THIS run: child processes, started before this process initialises the GPU
-    pmc, pmc_note = None, None
+    pmc, pmc_note, extra_pmc = None, None, {}
     if world == 1 and args.pmc in ("auto", "live"):
         if under_a_profiler():
             pmc_note = "bench.py itself runs below a profiler: no nested passes"
         else:
             pmc, pmc_note = pmc_live(args)
-    run_ranks(args, json_fd, world, rank, local_rank, distributed, pmc, pmc_note)
+            if pmc is not None and not distributed and not args.no_extra_configs:      # one sq pass per extra configuration, same rule (child processes, now)
+                import pmc_passes
+                for name, (scene_id, W, H, S, B, prec) in EXTRA_CONFIGS:
+                    cfg = dict(pmc_config(args), scene_id=scene_id, width=W, height=H, samples=S, bounces=B, precision=prec, threads=0)
+                    try:
+                        extra_pmc[name] = pmc_passes.collect(cfg, passes=("sq",), reps=2, timeout=240)
+                    except Exception:
+                        pass
+    run_ranks(args, json_fd, world, rank, local_rank, distributed, pmc, pmc_note, extra_pmc)
 
 
 if __name__ == "__main__":

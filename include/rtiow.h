@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RTIOW_ABI_VERSION 4
+#define RTIOW_ABI_VERSION 5
 
 #define RTIOW_E_BADARG   (-1)
 #define RTIOW_E_STATE    (-2)   /* call order violated (e.g. render before set_scene) */
@@ -124,8 +124,11 @@ typedef struct {
     /* RTIOW_SCHED_SORTED: 1 when the main launch stored finished pixels in slot order into a staging buffer and
      * place_pixels_kernel wrote the image in whole lines (coalesced framebuffer writes); place_ms = HIP-event time of
      * that kernel in the last timed render (inside render_ms, outside main_ms). */
-    int32_t  staged_stores, reserved0;
+    int32_t  staged_stores;
+    int32_t  num_cus;            /* compute units of the handle's device (hipDeviceProp_t::multiProcessorCount)              */
     double   place_ms;
+    int32_t  clock_mhz;          /* its nominal shader clock (hipDeviceProp_t::clockRate): what an issue-slot figure is rated against */
+    int32_t  reserved0;
 } rtiow_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------

@@ -119,13 +119,14 @@ __global__ void __launch_bounds__(1024) cost_scatter_kernel(const uint32_t* __re
     // are neighbours in the image and equal in cost get adjacent ranks (see `group` below).
     const int st_x = (W + 63) >> 6;
     const int sx = (int)blockIdx.x % st_x, sy = (int)blockIdx.x / st_x;
-    int bins[SCATTER_PER_THREAD], pix[SCATTER_PER_THREAD];
+    int bins[SCATTER_PER_THREAD], pix[SCATTER_PER_THREAD], packed_px[SCATTER_PER_THREAD];   // packed: what the render kernel's hand-out reads, (row << 16 | column)
 #pragma unroll
     for (int u = 0; u < SCATTER_PER_THREAD; ++u) {
         const int idx = u * (int)blockDim.x + (int)threadIdx.x, tile = idx >> 6, within = idx & 63;
         const int px = sx * 64 + (tile & 7) * 8 + (within & 7), py = sy * 64 + (tile >> 3) * 8 + (within >> 3);
         const int k = (px < W && py < rows) ? py * W + px : -1;
         pix[u] = k;
+        packed_px[u] = (py << 16) | px;
         bins[u] = -1;
         if (k >= 0) {
             bins[u] = cost_bin(cost[k]);
@@ -145,14 +146,15 @@ __global__ void __launch_bounds__(1024) cost_scatter_kernel(const uint32_t* __re
         if (bins[u] < 0) continue;
         const int k = pix[u];
         int r = (int)(base[bins[u]] + atomicAdd(&local[bins[u]], 1u));   // sorted rank (order inside a bin is immaterial)
-        if (r < solo_slots) { order[r] = k; if (slot_of) slot_of[k] = r; continue; }   // the heaviest pixels: slot = rank, handed to the solo waves
+        const int packed = packed_px[u];
+        if (r < solo_slots) { order[r] = packed; if (slot_of) slot_of[k] = r; continue; }   // the heaviest pixels: slot = rank, handed to the solo waves
         r -= solo_slots;
         const int blk = r / per_block, q = r - blk * per_block;
         const int pools_here = (blk + 1) * pools_per_block <= total_pools ? pools_per_block : total_pools - blk * pools_per_block;
         const int g = q / group, j = q - g * group;                 // groups of `group` consecutive ranks stay together
         const int pool = blk * pools_per_block + g % pools_here;
         const int lane_slot = (g / pools_here) * group + j;
-        order[solo_slots + pool * POOL + lane_slot] = k;
+        order[solo_slots + pool * POOL + lane_slot] = packed;
         if (slot_of) slot_of[k] = solo_slots + pool * POOL + lane_slot;       // the inverse, for place_pixels_kernel
     }
 }

@@ -93,6 +93,7 @@ __device__ __forceinline__ void cell_tests(const T* aos, unsigned rec_lo, unsign
 // Clip of o + t d against [lo, hi] on one axis, folded into [t0, t1].  Raw reciprocal: see eps above.
 // Returns the raw reciprocal of d it used (0 for a parallel ray): the walk steps with the same values.
 __device__ __forceinline__ float clip_axis(float o, float d, float lo, float hi, float& t0, float& t1) {
+#ifdef RTIOW_CLIP_BRANCHES
     if (__builtin_fabsf(d) < 1e-30f) {
         if (!(o >= lo && o <= hi)) t1 = -__builtin_huge_valf();
         return 0.0f;
@@ -102,6 +103,19 @@ __device__ __forceinline__ float clip_axis(float o, float d, float lo, float hi,
     t0 = __builtin_fmaxf(t0, __builtin_fminf(ta, tb));
     t1 = __builtin_fminf(t1, __builtin_fmaxf(ta, tb));
     return inv;
+#else
+    // The same, predicated: the parallel-ray case is three selects instead of a divergent region per axis (exec-mask
+    // save / branch / restore, ~8 scalar instructions each, for a case no camera ray takes).
+    const bool par = __builtin_fabsf(d) < 1e-30f;
+    const float inv = __builtin_amdgcn_rcpf(d);
+    const float ta = (lo - o) * inv, tb = (hi - o) * inv;
+    const float n0 = __builtin_fmaxf(t0, __builtin_fminf(ta, tb));
+    const float n1 = __builtin_fminf(t1, __builtin_fmaxf(ta, tb));
+    const bool inside = o >= lo && o <= hi;
+    t0 = par ? t0 : n0;
+    t1 = par ? (inside ? t1 : -__builtin_huge_valf()) : n1;
+    return par ? 0.0f : inv;
+#endif
 }
 
 template <class T>

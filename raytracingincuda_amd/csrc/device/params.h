@@ -54,7 +54,7 @@ template <class T> struct ColdParams {
     const unsigned char* __restrict__ mid_in;   // main launch: state at sample s_begin (nullptr: rng_in, zero sum)
     unsigned char* __restrict__ mid_out;        // prepass: park the state (nullptr: final launch, the pixel is stored)
     uint32_t* __restrict__ cost_out;  // prepass only: segments the pixel ran in this launch
-    const int* __restrict__ order;    // slot -> local pixel (or -1), nullptr: 8x8 tiles bottom-up
+    const int* __restrict__ order;    // slot -> local pixel as (local row << 16 | column), or -1; nullptr: 8x8 tiles bottom-up (frames wider than 65535 or taller than 32767 keep the tile order)
     // Main launch of the sorted schedule: a finished pixel is stored at its SLOT in a staging buffer (`fb` then points
     // there), not at its place in the image.  Lanes store 12-byte pixels whenever they finish; in image order the
     // partial lines of neighbouring pixels come from different waves on different XCDs (1.8 x write amplification,

@@ -212,14 +212,14 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
                     int jl;
                     bool valid;
                     if (c.order) {                               // cost-sorted hand-out (main launch of the sorted schedule)
-                        const int px = c.order[slot];
+                        const int px = c.order[slot];            // (row << 16 | column): no division by the image width here
                         valid = px >= 0;
-                        jl = valid ? px / c.W : 0;
-                        i = valid ? px - jl * c.W : 0;
+                        jl = valid ? px >> 16 : 0;
+                        i = valid ? px & 0xffff : 0;
                     } else valid = tile_slot_pixel(c, slot, i, jl);   // 8x8 tiles, bottom-up
                     if (valid) {
                         want = false;
-                        j = global_row(jl, c.strip_rows, c.nranks, c.rank);
+                        j = c.nranks == 1 ? jl : global_row(jl, c.strip_rows, c.nranks, c.rank);
                         lp = (size_t)jl * c.W + i;
                         if (c.mid_in) unpark_state<T>(c.mid_in, lp, st);
                         else {

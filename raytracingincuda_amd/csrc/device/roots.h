@@ -84,7 +84,18 @@ __device__ __forceinline__ void ieee_roots(int s, T h, T disc, T a, T& closest, 
 template <class T, bool ANYORDER = false>
 __device__ __forceinline__ void finish_sphere_test(int s, T h, T disc, T a, T& closest, int& hit, FastDiv<T> fd = FastDiv<T>{(T)0, false}) {
     PATH_STAT(PS_FINISH_CALL);
-    if (root_pretest_rejects<T>(h, disc, a, closest)) return;
+    // The pre-test pays in front of the full IEEE sequences (two divisions of 11 instructions, a square root of 15).  With the
+    // segment's shared reciprocal (fd.on: hit_world_grid) the block it guards is 26 straight-line instructions -- short square
+    // root, both quotients, the interval tests as selects -- and the 13 of the pre-test plus its divergent region cost more than
+    // they save: -2.5 % vector and -6 % scalar instructions, -2.8 % time on the headline frame, -3.9 % on the 487-sphere scene
+    // (profiles/r04/ab_second_root.jsonl; round 2 measured "no pre-test" at equal time when the block still branched around
+    // its second quotient).  -DRTIOW_R03_ROOT_FINISH restores round 3's form for A/B runs.
+#ifdef RTIOW_R03_ROOT_FINISH
+    const bool pretest = true;
+#else
+    const bool pretest = !fd.on;
+#endif
+    if (pretest && root_pretest_rejects<T>(h, disc, a, closest)) return;
     ieee_roots<T, ANYORDER>(s, h, disc, a, closest, hit, fd);
 }
 
@@ -100,10 +111,22 @@ __device__ __forceinline__ void ieee_roots(int s, T h, T disc, T a, T& closest, 
         sq = Real<T>::sqrt(disc);
     T root = fd.on ? shared_rcp_quotient(h - sq, a, fd.ra) : (h - sq) / a;   // :53
     auto inside = [&](T r) {
-        if (ANYORDER) return (tmin < r) && (r < closest || (r == closest && (unsigned)s < (unsigned)hit));
-        return (tmin < r) && (r < closest);
+        // bitwise on purpose: `&&` / `||` here compile to nested divergent regions (a dozen scalar instructions per evaluation),
+        // the comparisons have no side effects
+        if (ANYORDER) return (bool)((int)(tmin < r) & ((int)(r < closest) | ((int)(r == closest) & (int)((unsigned)s < (unsigned)hit))));
+        return (bool)((int)(tmin < r) & (int)(r < closest));
     };
     bool ok = inside(root);                                         // :54
+#ifndef RTIOW_R03_ROOT_FINISH
+    if (fd.on) {
+        // with the shared reciprocal the far root is five instructions: computed for every lane and selected, instead of a
+        // divergent region (exec-mask save / branch / restore) around them
+        const T far_root = shared_rcp_quotient(h + sq, a, fd.ra);   // :55
+        const bool far_ok = inside(far_root);                       // :56
+        root = ok ? root : far_root;
+        ok = (bool)((int)ok | (int)far_ok);
+    } else
+#endif
     if (!ok) {
         PATH_STAT(PS_SECOND_DIV);
         root = fd.on ? shared_rcp_quotient(h + sq, a, fd.ra) : (h + sq) / a;   // :55

@@ -14,6 +14,25 @@ template <class T> struct PathState {
     Rng rs;
 };
 
+// camera.h:121-123: `double a = 0.5 * (unit_direction.y() + 1.0)` and the two blend weights `(T)(1.0 - a)`, `(T)a`.
+// fp32 build: y is a float in [-1, 1], so y + 1.0 and 1.0 - y are exact in double, halving is exact, and the only rounding is the
+// conversion back to float -- which is what the float additions (1 + y), (1 - y) round to, halved exactly (both results are 0 or
+// >= 2^-25, no denormals).  Four float operations instead of two conversions up, three double operations and two conversions
+// down; the same bits (the oracle computes the double form; the full-frame goldens compare every pixel).
+__device__ __forceinline__ void sky_weights(float uy, float& w1, float& w2) {
+#ifdef RTIOW_SKY_BLEND_IN_DOUBLE
+    const double a_sky = 0.5 * ((double)uy + 1.0);
+    w1 = (float)(1.0 - a_sky); w2 = (float)a_sky;
+#else
+    w2 = 0.5f * (uy + 1.0f);
+    w1 = 0.5f * (1.0f - uy);
+#endif
+}
+__device__ __forceinline__ void sky_weights(double uy, double& w1, double& w2) {
+    const double a_sky = 0.5 * (uy + 1.0);
+    w1 = 1.0 - a_sky; w2 = a_sky;
+}
+
 // Everything after hit_world in one trip of the loop at camera.h:84: sky on a miss (camera.h:120-124), else hit
 // record + scatter (camera.h:88-117).  Returns true when the path ended; `col` is then its colour.
 //
@@ -30,8 +49,8 @@ __device__ __forceinline__ bool shade_step(const RenderParams<T>& p, const T* ld
     const V3<T> O = st.O, D = st.D;
     if (hit < 0) {
         PATH_STAT(PS_SKY);
-        const double a_sky = 0.5 * ((double)st.sky_uy + 1.0);                // camera.h:120-124, from the PRIMARY ray
-        const T w1 = (T)(1.0 - a_sky), w2 = (T)a_sky;
+        T w1, w2;
+        sky_weights(st.sky_uy, w1, w2);                                      // camera.h:120-124, from the PRIMARY ray
         const V3<T> sky = {RT_FMA(w2, (T)0.5, w1), RT_FMA(w2, (T)0.7, w1), RT_FMA(w2, (T)1.0, w1)};
         col = {st.atten.x * sky.x, st.atten.y * sky.y, st.atten.z * sky.z};
         return true;
@@ -96,7 +115,7 @@ __device__ __forceinline__ bool shade_step(const RenderParams<T>& p, const T* ld
         if (mtype == RTIOW_LAMBERTIAN) {                                 // material.h:38-49
             nd = {nrm.x + ruv.x, nrm.y + ruv.y, nrm.z + ruv.z};
             const T e = Real<T>::near_zero;
-            if (Real<T>::fabs(nd.x) < e && Real<T>::fabs(nd.y) < e && Real<T>::fabs(nd.z) < e) nd = nrm;
+            if ((int)(Real<T>::fabs(nd.x) < e) & (int)(Real<T>::fabs(nd.y) < e) & (int)(Real<T>::fabs(nd.z) < e)) nd = nrm;
         } else {                                                         // material.h:51-59
             PATH_STAT(PS_METAL);
             const V3<T> ur = unit3(reflect3(D, nrm));
@@ -124,8 +143,8 @@ __device__ __forceinline__ int shade_front(const RenderParams<T>& p, const T* ld
     const V3<T> O = st.O, D = st.D;
     if (hit < 0) {
         PATH_STAT(PS_SKY);
-        const double a_sky = 0.5 * ((double)st.sky_uy + 1.0);                // camera.h:120-124, from the PRIMARY ray
-        const T w1 = (T)(1.0 - a_sky), w2 = (T)a_sky;
+        T w1, w2;
+        sky_weights(st.sky_uy, w1, w2);                                      // camera.h:120-124, from the PRIMARY ray
         const V3<T> sky = {RT_FMA(w2, (T)0.5, w1), RT_FMA(w2, (T)0.7, w1), RT_FMA(w2, (T)1.0, w1)};
         col = {st.atten.x * sky.x, st.atten.y * sky.y, st.atten.z * sky.z};
         return SF_TERMINATED;
@@ -195,7 +214,7 @@ __device__ __forceinline__ bool shade_back(PathState<T>& st, const ShadeCarry<T>
     if (sc.mtype == RTIOW_LAMBERTIAN) {                                  // material.h:38-49
         nd = {nrm.x + ruv.x, nrm.y + ruv.y, nrm.z + ruv.z};
         const T e = Real<T>::near_zero;
-        if (Real<T>::fabs(nd.x) < e && Real<T>::fabs(nd.y) < e && Real<T>::fabs(nd.z) < e) nd = nrm;
+        if ((int)(Real<T>::fabs(nd.x) < e) & (int)(Real<T>::fabs(nd.y) < e) & (int)(Real<T>::fabs(nd.z) < e)) nd = nrm;
     } else {                                                             // material.h:51-59
         PATH_STAT(PS_METAL);
         const V3<T> ur = unit3(reflect3(st.D, nrm));

@@ -157,7 +157,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         p.cold.s_begin = 0; p.s_end = S; p.cold.rng_in = h->rng; p.cold.mid_in = nullptr; p.cold.mid_out = nullptr;
         p.cold.cost_out = nullptr; p.cold.order = nullptr; p.cold.total_slots = (int)tile_slots; p.cold.first_pools = 0;
         p.cold.solo_waves = 0; p.cold.solo_lanes = 1; p.cold.stage_by_slot = 0;
-        if (h->schedule == RTIOW_SCHED_SORTED && SA > 0 && npix >= 4096) {
+        if (h->schedule == RTIOW_SCHED_SORTED && SA > 0 && npix >= 4096 && p.cold.W < 65536 && h->local_rows < 32768) {   // (the order's entries are row << 16 | column)
             phases = 2;
             const int total_pools = (npix + POOL - 1) / POOL;
             int rc;

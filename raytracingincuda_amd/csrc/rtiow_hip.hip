@@ -151,7 +151,11 @@ int rtiow_create(int device, int precision, rtiow_handle* out) {
         (void)hipGetLastError();
     }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+        h->num_cus = prop.multiProcessorCount;
+        h->stats.clock_mhz = prop.clockRate / 1000;
+    }
+    h->stats.num_cus = h->num_cus;
     *out = h;
     return 0;
 }

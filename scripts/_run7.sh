@@ -1,0 +1,7 @@
+set -e
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r04
+L=raytracingincuda_amd/lib/ab
+timeout -k 10 400 python scripts/ab_libs.py $L/r03_head.so $L/nodiv.so $L/nodiv_clip.so 2>&1 | tee gpurun_out/r04/ab_nodiv_clip.jsonl
+timeout -k 10 400 python scripts/ab_libs.py $L/r03_head.so $L/nodiv.so $L/nodiv_clip.so -- --w 3840 --h 2160 2>&1 | tee -a gpurun_out/r04/ab_nodiv_clip.jsonl
+timeout -k 10 600 python scripts/ab_pmc.py $L/nodiv.so $L/nodiv_clip.so --sets sq 2>&1 | tee gpurun_out/r04/pmc_nodiv_clip.jsonl

@@ -884,16 +884,40 @@ def test_bench_prints_one_contract_line(rt):
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
-    # frac is EXECUTED work: the vector-issue fraction from rocprofv3 --pmc passes this very run made over the loaded build
-    assert rf["frac"] is not None, rf["counters_from"]
-    assert rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1 and 0 < rf["launch_ms_mean"] <= d["kernel_ms_mean"]
-    assert rf["build_id"] == rt.build_id() and "rocprofv3" in rf["counters_from"]
+    assert rf["unit"] == "TFLOP/s" and 0 < rf["launch_ms_mean"] <= d["kernel_ms_mean"] and rf["device"]["cus"] > 0 and rf["device"]["clock_mhz"] > 0
+    assert rf["practical_peak"]["value"] > 0 and rf["algorithmic_frac"] > 0 and d["step"]["scene_prepare_ms"] > 0
+    # frac is EXECUTED work: the vector-issue fraction from rocprofv3 --pmc passes this very run made over the loaded build.  bench.py is built to
+    # degrade to null where the profiler cannot run (no permission, counter slots busy): the contract line must survive that (the live leg has its
+    # own test below, which skips there)
+    if rf["frac"] is None:
+        assert "live passes failed" in rf["counters_from"] or "no record" in rf["counters_from"], rf["counters_from"]
+    else:
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1
+        assert rf["build_id"] == rt.build_id()
+    # the other configurations of the round's claims ride along, rendered by the same library after the timed region
+    ex = {e["name"]: e for e in d["extra_configs"]}
+    assert set(ex) == {"fp64_headline", "scene1_487_spheres_1080p", "baseline_config2_scene1_320x192_10spp_25b"}
+    for e in ex.values():
+        assert e["ms_per_step"] > 0 and e["value"] > 0 and e["unit"] == "Mrays/s" and e["main_launch_ms"] <= e["ms_per_step"]
+        assert e["frac"] is None or 0 < e["frac"] < 1.2
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and cb["sample"]
+
+
+def test_bench_live_counter_passes(rt):
+    """The live leg of roofline.frac: rocprofv3 --pmc child passes over the loaded library (skips where the profiler cannot collect counters)."""
+    import json, sys
+    from tests.conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--width", "256", "--height", "144", "--samples", "64",
+                        "--bounces", "10", "--pmc", "live", "--no-cpu-baseline", "--no-extra-configs", "--no-scaling-probe"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rf = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])["roofline"]
+    if rf["frac"] is None and "live passes failed" in rf["counters_from"]:
+        pytest.skip("rocprofv3 --pmc is not usable here: " + rf["counters_from"][:200])
+    assert rf["frac"] is not None and "rocprofv3" in rf["counters_from"] and rf["build_id"] == rt.build_id()
     iss = rf["issued"]
     assert iss["valu_wave_insts_per_launch"] > 1e6 and abs(iss["valu_issue_frac"] - rf["frac"]) < 1e-3 and 0 < iss["active_lane_frac"] <= 1
     assert rf["traffic"] > 0 and rf["write_bytes"] >= 256 * 144 * 12 * 0.9
-    assert rf["algorithmic_frac"] > 0 and d["step"]["scene_prepare_ms"] > 0
-    cb = d["cpu_baseline"]
-    assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and cb["sample"]
 
 
 def test_bench_two_rank_rehearsal(rt):

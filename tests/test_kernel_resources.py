@@ -74,3 +74,18 @@ def test_design_md_quotes_the_committed_kernel(kernel_metadata):
     m = re.search(r"render_persistent_kernel<float>`?: (\d+) VGPRs, (\d+) SGPR spills.*?render_persistent_kernel<double>`?: (\d+) VGPRs, (\d+) SGPR spills", text, re.S)
     assert m, "DESIGN.md §4.5 must carry the line `render_persistent_kernel<float>: N VGPRs, M SGPR spills ... render_persistent_kernel<double>: ...`"
     assert (int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4))) == (f32["vgpr"], f32["sgpr_spill"], f64["vgpr"], f64["sgpr_spill"])
+
+
+def test_fp64_issue_fraction_uses_the_kernels_own_double_precision_share(kernel_metadata):
+    """bench.py charges the fp64 main kernel's double-precision instructions 4 issue cycles and the others 2 (roofline.frac);
+    FP64_KERNEL_DP_SHARE must be the share in the compiler's output for that kernel."""
+    import bench
+    _, text = kernel_metadata
+    sym = [l for l in text.splitlines() if l.startswith("_ZN") and "render_persistent_kernelIdLi0ELb0E" in l and l.rstrip().split()[0].endswith(":")]
+    assert len(sym) == 1, sym
+    start = text.index("\n" + sym[0].split()[0])
+    body = text[start:text.index(".Lfunc_end", start)]
+    valu = [l.split()[0] for l in body.splitlines() if l.startswith("\tv_")]
+    dp = [op for op in valu if re.search(r"_f64|_[bui]64", op)]
+    share = len(dp) / len(valu)
+    assert abs(share - bench.FP64_KERNEL_DP_SHARE) <= 0.04, (share, len(valu))

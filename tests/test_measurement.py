@@ -94,9 +94,17 @@ def test_roofline_frac_is_executed_work_or_null():
     rf = bench.roofline_object(_args(), st, 468_000_000, main_ms, pmc, "test", 1)
     assert rf["frac"] == pytest.approx(0.5, abs=1e-4) and rf["achieved"] == pytest.approx(0.5 * 157.3, rel=1e-3) and rf["peak"] == 157.3
     assert rf["issued"]["valu_issue_frac"] == pytest.approx(rf["frac"], abs=1e-4) and rf["traffic"] == 2.0e8 and rf["write_bytes"] == 2.7e7
-    # fp64: the same issue fraction against the fp64 peak (an fp64 FMA slot is half as many flops per second)
+    assert rf["practical_peak"]["value"] == bench.PRACTICAL_FMA_TFLOPS[32] and rf["practical_peak"]["frac_of_practical"] == pytest.approx(0.5 * 157.3 / bench.PRACTICAL_FMA_TFLOPS[32], rel=1e-3)
+    assert rf["issued"]["cycles_per_inst_charged"] == 2.0
+    # fp64: the kernel's double-precision instructions (FP64_KERNEL_DP_SHARE of them) are charged 4 cycles, the others 2 (the
+    # text said "fp64: 4" while every instruction was charged 2); achieved = frac x the fp64 peak, and the text says what is computed
     rf64 = bench.roofline_object(_args(precision=64), st, 468_000_000, main_ms, pmc, "test", 1)
-    assert rf64["frac"] == pytest.approx(0.5, abs=1e-4) and rf64["peak"] == 78.6
+    cpi = 2.0 + 2.0 * bench.FP64_KERNEL_DP_SHARE
+    assert rf64["frac"] == pytest.approx(0.5 * cpi / 2.0, abs=1e-4) and rf64["peak"] == 78.6
+    assert rf64["achieved"] == pytest.approx(rf64["frac"] * 78.6, rel=1e-3) and rf64["issued"]["cycles_per_inst_charged"] == pytest.approx(cpi, abs=1e-3)
+    assert rf64["issued"]["valu_issue_frac"] == pytest.approx(0.5, abs=1e-4)          # the 2-cycle figure stays beside it
+    assert "%.2f cycles per instruction" % cpi in rf64["achieved_is"] and "charged 4" in rf64["achieved_is"]
+    assert bench.issue_fraction(6.144e9, 10.0, 32) == (pytest.approx(0.5), 2.0)
     # more than one rank: no counter figure at all
     assert bench.roofline_object(_args(), st, 468_000_000, main_ms, pmc, "test", 2)["frac"] is None
 
