@@ -197,6 +197,12 @@ int rtiow_bind_framebuffer(rtiow_handle h, void* device_ptr, size_t bytes);
 int rtiow_framebuffer_device_ptr(rtiow_handle h, void** device_ptr, size_t* bytes);
 /* D2H copy of the local rows (replaces the managed-memory read at main.cu:373). */
 int rtiow_read_framebuffer(rtiow_handle h, void* host_rgb, size_t bytes);
+/* The writer's quantisation done on the device (main.cu:367, 374-376: int(256 * clamp(c, 0.000, 0.999)) per channel, in T, truncated) and
+ * the local rows read back as one byte per channel: local_rows x width x 3 bytes, a quarter (fp32) or an eighth (fp64) of
+ * rtiow_read_framebuffer's bytes.  *nan_channels = channels holding a NaN (their level is int(NaN), undefined in the reference; its x86 build
+ * prints -2147483648): when it is not 0 the bytes of those channels mean nothing -- read the T framebuffer and use the T writer
+ * (rtiow_host_write_ppm), which prints what the reference prints.  The host writers for levels: rtiow_host_write_ppm_levels. */
+int rtiow_read_levels(rtiow_handle h, unsigned char* host_levels, size_t bytes, uint64_t* nan_channels);
 
 /* ---- knobs / introspection */
 int rtiow_set_scene_source(rtiow_handle h, int scene_source /* RTIOW_SCENE_* */);

@@ -47,6 +47,12 @@ int rtiow_host_format_ppm(int precision, int width, int height, const void* rgb,
 /* Binary variant (not in the reference): "P6\nW H\n255\n" + one byte per channel, the same
  * int(256*clamp(c, 0.000, 0.999)) levels; ~12x smaller and faster than the text file. */
 int rtiow_host_write_ppm_binary(const char* path, int precision, int width, int height, const void* rgb);
+/* The same two files from LEVELS (one byte per channel, 0..255: rtiow_read_levels, or rtiow_host_levels below): text P3 (binary = 0; formatted
+ * by up to 16 threads, every thread writing its own range of the file) or P6 (binary = 1).  Byte-identical to the writers above for frames
+ * without NaN channels. */
+int rtiow_host_write_ppm_levels(const char* path, int width, int height, const unsigned char* levels, int binary);
+/* main.cu:367, 374-376 per channel on the host: levels[k] = int(256 * clamp(rgb[k], 0.000, 0.999)); returns the number of NaN channels (their byte is 0). */
+long long rtiow_host_levels(int precision, int width, int height, const void* rgb, unsigned char* levels);
 
 /* Row sharding used by rtiow_set_shard (rtiow.h): strips of strip_rows rows dealt round-robin.
  * Writes the global row index of every local row of `rank` (rows_out may be NULL) and returns

@@ -86,7 +86,7 @@ HIP_SYMBOLS = [
     "rtiow_abi_version", "rtiow_build_id", "rtiow_create", "rtiow_destroy", "rtiow_last_error_string", "rtiow_set_stream",
     "rtiow_set_scene", "rtiow_set_camera", "rtiow_set_shard", "rtiow_local_rows", "rtiow_local_row_map",
     "rtiow_init_rng", "rtiow_render", "rtiow_count_segments", "rtiow_bind_framebuffer", "rtiow_framebuffer_device_ptr",
-    "rtiow_read_framebuffer", "rtiow_set_scene_source", "rtiow_set_schedule", "rtiow_get_stats", "rtiow_synchronize",
+    "rtiow_read_framebuffer", "rtiow_read_levels", "rtiow_set_scene_source", "rtiow_set_schedule", "rtiow_get_stats", "rtiow_synchronize",
     "rtiow_debug_read_rng", "rtiow_debug_read_costs", "rtiow_debug_timeline", "rtiow_debug_ops", "rtiow_debug_jump_matrices", "rtiow_debug_grid_plan", "rtiow_debug_hit_world",
     "rtiow_render_async", "rtiow_render_wait", "rtiow_stream", "rtiow_device",
     "rtiow_group_create", "rtiow_group_create_error", "rtiow_group_destroy", "rtiow_group_last_error_string", "rtiow_group_size", "rtiow_group_member",
@@ -96,7 +96,7 @@ HIP_SYMBOLS = [
 ]
 HOST_SYMBOLS = [
     "rtiow_host_scene_slots", "rtiow_host_build_scene", "rtiow_host_camera", "rtiow_host_ppm_filename",
-    "rtiow_host_write_ppm", "rtiow_host_format_ppm", "rtiow_host_write_ppm_binary", "rtiow_host_shard_rows", "rtiow_host_place_rows",
+    "rtiow_host_write_ppm", "rtiow_host_format_ppm", "rtiow_host_write_ppm_binary", "rtiow_host_write_ppm_levels", "rtiow_host_levels", "rtiow_host_shard_rows", "rtiow_host_place_rows",
 ]
 
 _hip = None
@@ -296,6 +296,26 @@ def write_ppm(path, rgb, binary=False):
         raise RtiowError(rc, "Could not open file for writing: %s" % path)
 
 
+def levels(rgb):
+    """(levels, nan_channels): main.cu:367, 374-376 per channel on the host, uint8 [H, W, 3] (what rtiow_read_levels computes on the device)."""
+    rgb = np.ascontiguousarray(rgb)
+    lib = load_host_library()
+    lib.rtiow_host_levels.restype = ctypes.c_longlong
+    out = np.empty(rgb.shape, np.uint8)
+    n = lib.rtiow_host_levels(_rgb_precision(rgb), rgb.shape[1], rgb.shape[0], ctypes.c_void_p(rgb.ctypes.data), ctypes.c_void_p(out.ctypes.data))
+    if n < 0:
+        raise RtiowError(int(n), "rtiow_host_levels: bad arguments")
+    return out, int(n)
+
+
+def write_ppm_levels(path, lev, binary=False):
+    """The P3 / P6 file from levels (uint8 [H, W, 3]): threaded formatter, every thread writes its own range of the file."""
+    lev = np.ascontiguousarray(lev, np.uint8)
+    rc = load_host_library().rtiow_host_write_ppm_levels(os.fsencode(path), lev.shape[1], lev.shape[0], ctypes.c_void_p(lev.ctypes.data), 1 if binary else 0)
+    if rc:
+        raise RtiowError(rc, "Could not open file for writing: %s" % path)
+
+
 def shard_rows(height, rank, nranks, strip_rows=8):
     """Global row indices rendered by `rank` (same rule as rtiow_set_shard)."""
     lib = load_host_library()
@@ -448,6 +468,13 @@ class Renderer:
         if out.size:
             self._check(self._lib.rtiow_read_framebuffer(self._h, out.ctypes.data, out.nbytes))
         return out
+
+    def read_levels(self):
+        """(levels uint8 [rows, W, 3], nan_channels): the writer's quantisation done on the device (rtiow_read_levels)."""
+        out = np.empty((self.local_rows, self.width, 3), np.uint8)
+        nans = ctypes.c_uint64(0)
+        self._check(self._lib.rtiow_read_levels(self._h, ctypes.c_void_p(out.ctypes.data), ctypes.c_size_t(out.nbytes), ctypes.byref(nans)))
+        return out, int(nans.value)
 
     def synchronize(self):
         self._check(self._lib.rtiow_synchronize(self._h))

@@ -15,6 +15,32 @@ __device__ __forceinline__ void store_pixel(const COLD& c, size_t lp, V3<T> acc)
     o[2] = acc.z > (T)0 ? Real<T>::sqrt(acc.z) : (T)0;
 }
 
+// The writer's quantisation on the device (main.cu:367, 374-376; interval.h:25-29): level = int(256 * clamp(c, 0.000, 0.999)) per channel,
+// the same comparisons, the same multiplication in T and the same truncation as csrc/host/rtiow_host.cpp to_level -- so the drop-in
+// executable reads back one byte per channel instead of a T (rtiow_read_levels).  A NaN channel (undefined in the reference:
+// int(NaN)) is counted; the caller then takes the T framebuffer and the host writer, which prints what the reference's x86 build prints.
+template <class T>
+__global__ void __launch_bounds__(256) quantise_kernel(const T* __restrict__ fb, unsigned char* __restrict__ levels, size_t n, unsigned long long* __restrict__ nan_channels) {
+    const size_t k0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (k0 >= n) return;
+    unsigned word = 0, nans = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        unsigned level = 0;
+        if (k0 + u < n) {
+            const T c = fb[k0 + u];
+            const T lo = (T)0.000, hi = (T)0.999;
+            if (!(c == c)) ++nans;
+            const T cl = c < lo ? lo : (c > hi ? hi : c);
+            level = (unsigned)(int)((T)256 * cl) & 255u;
+        }
+        word |= level << (8 * u);
+    }
+    if (k0 + 4 <= n) *reinterpret_cast<unsigned*>(levels + k0) = word;          // k0 is a multiple of 4, the buffer 256-byte aligned
+    else for (int u = 0; k0 + u < n; ++u) levels[k0 + u] = (unsigned char)(word >> (8 * u));
+    if (nans) atomicAdd(nan_channels, (unsigned long long)nans);
+}
+
 template <class T, int SRC>
 __device__ __forceinline__ T* stage_scene(const RenderParams<T>& p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

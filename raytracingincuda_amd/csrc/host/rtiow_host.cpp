@@ -4,6 +4,12 @@
 // host code is compiled by g++ for x86-64 without FMA.
 #include "rtiow_host.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+#include <sys/types.h>
+
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -330,6 +336,92 @@ int rtiow_host_write_ppm_binary(const char* path, int precision, int width, int 
     if (!f) return RTIOW_E_STATE;
     const bool ok = std::fwrite(s.data(), 1, s.size(), f) == s.size();
     return (std::fclose(f) == 0 && ok) ? 0 : RTIOW_E_STATE;
+}
+
+long long rtiow_host_levels(int precision, int width, int height, const void* rgb, unsigned char* levels) {
+    if (!rgb || !levels || width <= 0 || height <= 0 || (precision != 32 && precision != 64)) return -1;
+    const size_t n = (size_t)width * height * 3;
+    long long nans = 0;
+    for (size_t k = 0; k < n; ++k) {
+        const int level = precision == 32 ? to_level<float>(((const float*)rgb)[k]) : to_level<double>(((const double*)rgb)[k]);
+        if (level < 0) { ++nans; levels[k] = 0; } else levels[k] = (unsigned char)level;
+    }
+    return nans;
+}
+
+int rtiow_host_write_ppm_levels(const char* path, int width, int height, const unsigned char* levels, int binary) {
+    if (!path || !levels || width <= 0 || height <= 0) return RTIOW_E_BADARG;
+    const size_t npix = (size_t)width * height;
+    char head[64];
+    const int hn = std::snprintf(head, sizeof head, "%s\n%d %d\n255\n", binary ? "P6" : "P3", width, height);
+    const int fd = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);          // read access too: the text body is written through a mapping
+    if (fd < 0) return RTIOW_E_STATE;
+    auto write_all = [fd](const char* d, size_t n, off_t at) {
+        while (n) {
+            const ssize_t w = ::pwrite(fd, d, n, at);
+            if (w <= 0) return false;
+            d += w; n -= (size_t)w; at += w;
+        }
+        return true;
+    };
+    bool ok = write_all(head, (size_t)hn, 0);
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt < 1 || npix < 65536) nt = 1;
+    if (binary) {
+        // the levels ARE the file's body: ranges of it written by nt threads (page-cache copies scale with the threads)
+        std::vector<std::thread> th;
+        std::vector<char> good(nt, 1);
+        const size_t n = npix * 3;
+        for (unsigned k = 0; k < nt; ++k) {
+            const size_t a = n * k / nt, b = n * (k + 1) / nt;
+            auto job = [&, a, b, k]() { good[k] = write_all((const char*)levels + a, b - a, (off_t)hn + (off_t)a); };
+            if (k + 1 < nt) th.emplace_back(job); else job();
+        }
+        for (auto& t : th) t.join();
+        for (char g : good) ok = ok && g;
+    } else {
+        // text: the frame is cut into ranges; worker threads format them ("r g b\n", main.cu:372-377) while this thread writes every
+        // finished range in file order.  The file system's buffered write is the floor (23 MB of text at 1080p: 6.5-9 ms on the GPU
+        // boxes' overlay; several threads writing one file are serialised by its lock, and formatting through a shared mapping of the
+        // file took twice as long: profiles/r04/e2e_*.log), so the formatting -- 1-2 ms on 15 threads -- hides behind it.
+        const LevelText* tab = level_table();
+        const unsigned workers = nt > 1 ? nt - 1 : 1;
+        const unsigned nr = nt > 1 ? 4 * workers : 1;                 // ranges: four rounds per worker, so that the first write starts early
+        std::vector<std::unique_ptr<char[]>> buf(nr);
+        std::vector<size_t> len(nr, 0);
+        auto format = [&](unsigned k) {
+            const size_t p0 = npix * k / nr, p1 = npix * (k + 1) / nr;
+            buf[k].reset(new char[(p1 - p0) * 12 + 16]);
+            char* w = buf[k].get();
+            const unsigned char* v = levels + 3 * p0;
+            for (size_t p = p0; p < p1; ++p, v += 3) {
+                const LevelText& r = tab[v[0]]; std::memcpy(w, r.s, 4); w += r.n; *w++ = ' ';
+                const LevelText& g = tab[v[1]]; std::memcpy(w, g.s, 4); w += g.n; *w++ = ' ';
+                const LevelText& b = tab[v[2]]; std::memcpy(w, b.s, 4); w += b.n; *w++ = '\n';
+            }
+            len[k] = (size_t)(w - buf[k].get());
+        };
+        off_t pos = hn;
+        if (nt == 1) {
+            format(0);
+            ok = ok && write_all(buf[0].get(), len[0], pos);
+        } else {
+            std::vector<std::atomic<int>> done(nr);
+            for (auto& d : done) d.store(0);
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < workers; ++t)
+                th.emplace_back([&, t]() { for (unsigned k = t; k < nr; k += workers) { format(k); done[k].store(1, std::memory_order_release); } });
+            for (unsigned k = 0; k < nr; ++k) {
+                while (!done[k].load(std::memory_order_acquire)) std::this_thread::yield();
+                ok = ok && write_all(buf[k].get(), len[k], pos);
+                pos += (off_t)len[k];
+                buf[k].reset();
+            }
+            for (auto& t : th) t.join();
+        }
+    }
+    return (::close(fd) == 0 && ok) ? 0 : RTIOW_E_STATE;
 }
 
 int rtiow_host_shard_rows(int height, int rank, int nranks, int strip_rows, int32_t* rows_out) {

@@ -47,6 +47,7 @@ struct rtiow_handle_s {
     int schedule = RTIOW_SCHED_SORTED;
     unsigned char* mid = nullptr; size_t mid_bytes = 0;          // SCHED_SORTED: MidState records parked between the launches
     uint32_t* cost = nullptr; size_t cost_bytes = 0;
+    unsigned char* levels = nullptr; size_t levels_bytes = 0;     // rtiow_read_levels: one byte per channel + an 8-byte NaN counter behind them
     uint32_t* cost_rank = nullptr; size_t cost_rank_bytes = 0;    // the smoothed cost the sort ranks by
     int* order = nullptr; size_t order_bytes = 0;
     int* slot_of = nullptr; size_t slot_of_bytes = 0;            // SCHED_SORTED: pixel -> slot (the inverse of `order`)

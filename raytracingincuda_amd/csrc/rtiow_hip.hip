@@ -165,7 +165,7 @@ int rtiow_destroy(rtiow_handle h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     void* bufs[] = {h->geom_a, h->shade_tbl, h->geom_s, h->grid_blob, h->cost_rank, h->rng, h->jump, h->work_counter, h->mid, h->slot_of, h->staged,
-                    h->cost, h->order, h->sort_scratch, h->fb_external ? nullptr : h->fb};
+                    h->cost, h->order, h->sort_scratch, h->levels, h->fb_external ? nullptr : h->fb};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -415,6 +415,32 @@ int rtiow_read_framebuffer(rtiow_handle h, void* host_rgb, size_t bytes) {
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(host_rgb, h->fb, need, hipMemcpyDeviceToHost));   // blocking copy: pageable destination (measured 8.5 ms faster than the async call on a non-blocking stream)
+    return 0;
+}
+
+int rtiow_read_levels(rtiow_handle h, unsigned char* host_levels, size_t bytes, uint64_t* nan_channels) {
+    if (!h || !host_levels || !nan_channels) return RTIOW_E_BADARG;
+    if (!h->have_camera || !h->fb) return fail_arg(h, RTIOW_E_STATE, "rtiow_read_levels before rtiow_render");
+    const size_t n = (size_t)h->local_rows * img_w(h) * 3;
+    if (bytes < n) return fail_arg(h, RTIOW_E_BADARG, "rtiow_read_levels: host buffer too small");
+    *nan_channels = 0;
+    if (n == 0) return 0;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t padded = (n + 255) / 256 * 256;
+    int rc = ensure_buffer(h, &h->levels, &h->levels_bytes, padded + 256);
+    if (rc) return rc;
+    unsigned long long* counter = reinterpret_cast<unsigned long long*>(h->levels + padded);
+    HIP_TRY(h, hipMemsetAsync(counter, 0, sizeof(unsigned long long), h->stream));
+    const unsigned blocks = (unsigned)(((n + 3) / 4 + 255) / 256);
+    if (h->precision == 32) hipLaunchKernelGGL(quantise_kernel<float>, dim3(blocks), dim3(256), 0, h->stream, (const float*)h->fb, h->levels, n, counter);
+    else hipLaunchKernelGGL(quantise_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, (const double*)h->fb, h->levels, n, counter);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // one blocking copy of levels + counter (pageable destination, like rtiow_read_framebuffer)
+    HIP_TRY(h, hipMemcpy(host_levels, h->levels, n, hipMemcpyDeviceToHost));
+    unsigned long long nans = 0;
+    HIP_TRY(h, hipMemcpy(&nans, counter, sizeof nans, hipMemcpyDeviceToHost));
+    *nan_channels = nans;
     return 0;
 }
 

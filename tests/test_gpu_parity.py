@@ -865,6 +865,23 @@ def test_full_frames_match_the_oracle_row_by_row(rt, golden_dir, name):
     assert hashlib.sha256(np.ascontiguousarray(img).view(np.uint8).tobytes()).hexdigest() == g["sha256"]
 
 
+def test_levels_quantised_on_the_device_equal_the_host_writers(rt):
+    """rtiow_read_levels: int(256 * clamp(c, 0, 0.999)) per channel on the device == the host's to_level on the read-back framebuffer
+    (main.cu:367, 374-376), fp32 and fp64, full frame and shard; a NaN channel is counted."""
+    for prec in (32, 64):
+        with rt.Renderer(0, prec) as r:
+            r.set_camera(rt.camera(prec, 322, 183, 8, 10)); r.set_scene(rt.build_scene(3, prec)); r.init_rng(1227)
+            for shard in (None, (1, 3, 2)):
+                if shard:
+                    r.set_shard(*shard); r.init_rng(1227)
+                r.render(0)
+                fb = r.read_framebuffer()
+                lev, nans = r.read_levels()
+                want, host_nans = rt.levels(fb)
+                assert nans == 0 and host_nans == 0 and lev.shape == fb.shape and np.array_equal(lev, want)
+                assert lev.max() > 200 and lev.min() < 50
+
+
 def test_bench_prints_one_contract_line(rt):
     """bench.py's contract with the driver: exactly one JSON line on stdout with the agreed fields,
     the roofline of the dominant launch and the CPU baseline (small frame so the CPU leg takes a second)."""

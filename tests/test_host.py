@@ -121,6 +121,30 @@ def test_ppm_writer_threaded_ranges_keep_the_text(native, tmp_path):
         assert open(path, "rb").read() == want
 
 
+def test_level_writers_are_byte_identical_to_the_float_writers(native, tmp_path):
+    """The drop-in executable quantises on the device and writes the file from one byte per channel (rtiow_read_levels +
+    rtiow_host_write_ppm_levels, main.cu:364-379): same bytes as the writers that take the T framebuffer, text and binary, on frames
+    small (one thread) and large (16 formatting threads, each writing its own range of the file), incl. every level 0..255."""
+    rng = np.random.default_rng(11)
+    for dt in (np.float32, np.float64):
+        for shape in ((3, 5, 3), (301, 257, 3), (540, 960, 3)):
+            img = rng.uniform(-0.2, 1.2, shape).astype(dt)
+            flat = img.reshape(-1)
+            flat[:min(256, flat.size)] = ((np.arange(256) + 0.5) / 256.0)[:min(256, flat.size)]
+            lev, nans = native.levels(img)
+            assert nans == 0 and lev.dtype == np.uint8 and lev.shape == img.shape
+            assert np.array_equal(lev, np.trunc(dt(256) * np.clip(img, dt(0), dt(0.999))).astype(np.uint8))
+            for binary in (False, True):
+                a, b = str(tmp_path / "t.ppm"), str(tmp_path / "l.ppm")
+                native.write_ppm(a, img, binary=binary)
+                native.write_ppm_levels(b, lev, binary=binary)
+                assert open(a, "rb").read() == open(b, "rb").read()
+    img = np.zeros((2, 2, 3), np.float32); img[1, 0, 2] = np.nan
+    assert native.levels(img)[1] == 1                      # a NaN channel is reported: the caller takes the float writer
+    with pytest.raises(native.RtiowError):
+        native.write_ppm_levels(str(tmp_path / "no_such_dir" / "x.ppm"), np.zeros((1, 1, 3), np.uint8))
+
+
 def test_shard_rows_partition_and_place_rows(native):
     for H, n, strip in [(1080, 8, 8), (1080, 3, 8), (192, 2, 8), (50, 4, 8), (7, 3, 2), (5, 8, 8), (1080, 1, 8)]:
         seen = []
