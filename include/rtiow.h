@@ -213,36 +213,8 @@ int rtiow_synchronize(rtiow_handle h);
 int rtiow_stream(rtiow_handle h, void** hip_stream);   /* the hipStream_t the handle launches on */
 int rtiow_device(rtiow_handle h, int* device);
 
-/* ---- test hooks (used by tests/ only): device RNG states after rtiow_init_rng, as
- * local_pixels x 6 uint32 {v0..v4,d}; and elementwise device arithmetic probes that the
- * parity tests compare bit-for-bit with the host (op: 0 a/b, 1 sqrt(a), 2 fma(a,b,c),
- * 3 uniform(u32 a -> T), 4 a*b+c unfused). */
-int rtiow_debug_read_rng(rtiow_handle h, uint32_t* host_states, size_t count_words);
-/* After a render with RTIOW_SCHED_SORTED that sorted (rtiow_stats.phases == 2): per local pixel the prepass cost
- * (path segments of its prepass samples) and the key the sort ranked it by (the mean of that cost over the
- * pixel's neighbourhood inside its row strip, in quarter segments).  count = local pixels. */
-int rtiow_debug_read_costs(rtiow_handle h, uint32_t* own, uint32_t* smoothed, size_t count);
-/* Per-wave timeline of one (untimed, counting) persistent render: 8 words per wave
- * {t_start, t_pool_exhausted, t_end (100 MHz ticks), iterations alone, iterations cooperative,
- * pixels taken, 0, 0}. */
-int rtiow_debug_timeline(rtiow_handle h, int threads_per_block_row, uint64_t* out_words, size_t cap_words, int* waves);
-int rtiow_debug_ops(rtiow_handle h, int op, size_t n, const void* a, const void* b, const void* c, void* out);
-/* hit_world (hittable.h:80-98) alone, with the handle's scene and scene source, on n caller-supplied rays
- * {ox,oy,oz,dx,dy,dz} in the handle's precision: nearest root (+inf: none) and sphere index (-1: none) per ray.
- * Lets the tests compare the scene sources on rays no render produces. */
-int rtiow_debug_hit_world(rtiow_handle h, int n, const void* rays, void* t_out, int32_t* index_out);
-/* The 32 XORWOW subsequence-jump matrices A^(2^(67+b)) (160 x 5 words each) as the library builds
- * them: from its committed constant A^(2^67), or from_scratch != 0 from the one-step matrix A.
- * Host arithmetic only (no GPU needed).  Returns the number of matrices. */
-int rtiow_debug_jump_matrices(uint32_t* out_words, size_t cap_words, int from_scratch);
-/* The uniform-grid plan of RTIOW_SCENE_GRID for n spheres {cx,cy,cz,r} (doubles) around the recentring point
- * centre3, as the library builds it.  Host arithmetic only (no GPU needed).  dims4 = {nx, nz, registered
- * spheres, direct-list length}; params8 = {x0, z0, cell, slab ylo, slab yhi, Rfar, eps, Cmax}; cells (optional)
- * = nx*nz*4 sphere indices (0xffff x4: empty cell, n: pad); direct (optional) = the direct list; halfwidth
- * (optional, n entries) = registration half-width of every gridded sphere.  Returns 1 when the library would
- * use the grid for this scene, 0 when it keeps the screened loop, negative on bad arguments. */
-int rtiow_debug_grid_plan(int n, const double* center_radius, const double* centre3, int32_t* dims4, double* params8,
-                          uint16_t* cells, size_t cells_cap, int32_t* direct, size_t direct_cap, double* halfwidth);
+/* Test hooks (device RNG states, per-pixel costs, per-wave timeline, hit_world on caller-supplied rays, ...) are NOT part of this
+ * library's ABI: include/rtiow_debug.h declares them and only the test build (librtiow_hip_debug.so, -DRTIOW_DEBUG_API) exports them. */
 
 /* ======================================================================================
  * Multi-GPU inside one process (new work: the reference is single-GPU, main.cu:81).
@@ -311,13 +283,6 @@ int rtiow_group_read_framebuffer(rtiow_group g, void* host_rgb, size_t bytes);
 int rtiow_group_get_stats(rtiow_group g, rtiow_group_stats* out);
 /* Why RTIOW_GATHER_AUTO fell back to peer copies ("" if it did not). */
 const char* rtiow_group_transport_note(rtiow_group g);
-/* Test hook, host only (no GPU, no RCCL): the exchange's schedule -- the very function rtiow_group_gather runs --
- * against a recording table instead of HIP / RCCL, for n ranks on `devices` with `rows` local rows each.
- * mode = RTIOW_GATHER_RCCL | RTIOW_GATHER_PEER.  One record of 8 int64 per call (layout: csrc/rtiow_group.hip);
- * fail_at >= 0 makes that call fail.  Returns the number of records; *schedule_rc = what the schedule returned. */
-int rtiow_debug_gather_schedule(int n, const int* devices, const int* rows, int W, int precision, int mode, int fail_at,
-                                int64_t* records, size_t cap_records, int* schedule_rc);
-
 #ifdef __cplusplus
 }
 #endif

@@ -87,12 +87,16 @@ HIP_SYMBOLS = [
     "rtiow_set_scene", "rtiow_set_camera", "rtiow_set_shard", "rtiow_local_rows", "rtiow_local_row_map",
     "rtiow_init_rng", "rtiow_render", "rtiow_count_segments", "rtiow_bind_framebuffer", "rtiow_framebuffer_device_ptr",
     "rtiow_read_framebuffer", "rtiow_read_levels", "rtiow_set_scene_source", "rtiow_set_schedule", "rtiow_get_stats", "rtiow_synchronize",
-    "rtiow_debug_read_rng", "rtiow_debug_read_costs", "rtiow_debug_timeline", "rtiow_debug_ops", "rtiow_debug_jump_matrices", "rtiow_debug_grid_plan", "rtiow_debug_hit_world",
     "rtiow_render_async", "rtiow_render_wait", "rtiow_stream", "rtiow_device",
     "rtiow_group_create", "rtiow_group_create_error", "rtiow_group_destroy", "rtiow_group_last_error_string", "rtiow_group_size", "rtiow_group_member",
     "rtiow_group_set_scene", "rtiow_group_set_camera", "rtiow_group_set_scene_source", "rtiow_group_set_schedule",
     "rtiow_group_init_rng", "rtiow_group_render", "rtiow_group_gather", "rtiow_group_framebuffer_device_ptr",
-    "rtiow_group_read_framebuffer", "rtiow_group_get_stats", "rtiow_group_transport_note", "rtiow_debug_gather_schedule",
+    "rtiow_group_read_framebuffer", "rtiow_group_get_stats", "rtiow_group_transport_note",
+]
+# include/rtiow_debug.h: exported by lib/librtiow_hip_debug.so (the test build) only
+DEBUG_SYMBOLS = [
+    "rtiow_debug_read_rng", "rtiow_debug_read_costs", "rtiow_debug_timeline", "rtiow_debug_ops", "rtiow_debug_jump_matrices", "rtiow_debug_grid_plan", "rtiow_debug_hit_world",
+    "rtiow_debug_gather_schedule",
 ]
 HOST_SYMBOLS = [
     "rtiow_host_scene_slots", "rtiow_host_build_scene", "rtiow_host_camera", "rtiow_host_ppm_filename",
@@ -100,12 +104,15 @@ HOST_SYMBOLS = [
 ]
 
 _hip = None
+_hip_debug = None
 _host = None
 
 
 def lib_paths():
     # RTIOW_HIP_LIBRARY: another build of the same C-ABI (A/B timing of kernel variants, the stats build)
+    # "hip_debug": the test build (the same kernels + the hooks of include/rtiow_debug.h); RTIOW_HIP_DEBUG_LIBRARY: another build of it
     return {"hip": os.environ.get("RTIOW_HIP_LIBRARY") or os.path.join(_LIBDIR, "librtiow_hip.so"),
+            "hip_debug": os.environ.get("RTIOW_HIP_DEBUG_LIBRARY") or os.path.join(_LIBDIR, "librtiow_hip_debug.so"),
             "host": os.path.join(_LIBDIR, "librtiow_host.so")}
 
 
@@ -131,11 +138,12 @@ def load_host_library():
     return _host
 
 
-def load_hip_library():
-    """Load librtiow_hip.so.  Raises loudly when it is missing: there is no fallback path."""
-    global _hip
-    if _hip is None:
-        path = lib_paths()["hip"]
+def load_hip_library(debug=False):
+    """Load librtiow_hip.so -- or, debug=True, the test build librtiow_hip_debug.so, which also exports the hooks of
+    include/rtiow_debug.h.  Raises loudly when it is missing: there is no fallback path."""
+    global _hip, _hip_debug
+    if (_hip_debug if debug else _hip) is None:
+        path = lib_paths()["hip_debug" if debug else "hip"]
         if not os.path.exists(path):
             raise RtiowError(-100, "%s not built; run `python -m raytracingincuda_amd.build`" % path)
         lib = ctypes.CDLL(path)
@@ -164,10 +172,13 @@ def load_hip_library():
         lib.rtiow_set_schedule.argtypes = [H, ctypes.c_int, ctypes.c_int]
         lib.rtiow_get_stats.argtypes = [H, ctypes.POINTER(Stats)]
         lib.rtiow_synchronize.argtypes = [H]
-        lib.rtiow_debug_read_rng.argtypes = [H, ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t]
-        lib.rtiow_debug_read_costs.argtypes = [H, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t]
-        lib.rtiow_debug_timeline.argtypes = [H, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
-        lib.rtiow_debug_ops.argtypes = [H, ctypes.c_int, ctypes.c_size_t, vp, vp, vp, vp]
+        if debug:
+            lib.rtiow_debug_read_rng.argtypes = [H, ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t]
+            lib.rtiow_debug_read_costs.argtypes = [H, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t]
+            lib.rtiow_debug_timeline.argtypes = [H, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
+            lib.rtiow_debug_ops.argtypes = [H, ctypes.c_int, ctypes.c_size_t, vp, vp, vp, vp]
+            lib.rtiow_debug_gather_schedule.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                        ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
         lib.rtiow_render_async.argtypes = [H, ctypes.c_int]
         lib.rtiow_render_wait.argtypes = [H, ctypes.POINTER(ctypes.c_float)]
         lib.rtiow_stream.argtypes = [H, ctypes.POINTER(vp)]
@@ -193,10 +204,11 @@ def load_hip_library():
         lib.rtiow_group_framebuffer_device_ptr.argtypes = [G, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
         lib.rtiow_group_read_framebuffer.argtypes = [G, vp, ctypes.c_size_t]
         lib.rtiow_group_get_stats.argtypes = [G, ctypes.POINTER(GroupStats)]
-        lib.rtiow_debug_gather_schedule.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                                    ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
-        _hip = lib
-    return _hip
+        if debug:
+            _hip_debug = lib
+        else:
+            _hip = lib
+    return _hip_debug if debug else _hip
 
 
 def build_id():
@@ -341,8 +353,11 @@ def place_rows(full_rgb, local_rgb, rank, nranks, strip_rows):
 class Renderer:
     """One GPU's render state behind the C-ABI handle (include/rtiow.h)."""
 
-    def __init__(self, device=0, precision=32):
-        self._lib = load_hip_library()
+    def __init__(self, device=0, precision=32, debug=False):
+        """debug=True: the handle lives in the test build of the library (librtiow_hip_debug.so: the same kernels), whose hooks
+        (include/rtiow_debug.h) the debug_* methods call; the product library exports none of them."""
+        self._lib = load_hip_library(debug)
+        self._debug = bool(debug)
         self.precision = precision
         self.dtype = _dtype(precision)
         self._borrowed = False
@@ -358,6 +373,7 @@ class Renderer:
         """A view of a handle somebody else owns (a member of a RendererGroup): close() leaves it alone."""
         r = cls.__new__(cls)
         r._lib, r.precision, r.dtype, r._borrowed = lib, precision, _dtype(precision), True
+        r._debug = hasattr(lib, "rtiow_debug_ops") and lib is _hip_debug
         r._h = handle
         r.width, r.height = width, height
         return r
@@ -413,6 +429,7 @@ class Renderer:
 
     def debug_hit_world(self, rays):
         """hit_world alone on rays [n, 6] = {origin, direction}: (t [n], sphere index [n])."""
+        self._need_debug()
         dt = _dtype(self.precision)
         rays = np.ascontiguousarray(rays, dt)
         n = rays.shape[0]
@@ -476,6 +493,10 @@ class Renderer:
         self._check(self._lib.rtiow_read_levels(self._h, ctypes.c_void_p(out.ctypes.data), ctypes.c_size_t(out.nbytes), ctypes.byref(nans)))
         return out, int(nans.value)
 
+    def _need_debug(self):
+        if not getattr(self, "_debug", False):
+            raise RtiowError(-101, "test hook: librtiow_hip.so does not export it -- construct Renderer(device, precision, debug=True) (librtiow_hip_debug.so)")
+
     def synchronize(self):
         self._check(self._lib.rtiow_synchronize(self._h))
 
@@ -486,6 +507,7 @@ class Renderer:
 
     # -- test hooks
     def debug_read_rng(self):
+        self._need_debug()
         n = self.local_rows * self.width
         out = np.zeros((n, 6), np.uint32)
         self._check(self._lib.rtiow_debug_read_rng(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), out.size))
@@ -493,6 +515,7 @@ class Renderer:
 
     def debug_read_costs(self):
         """(own, smoothed) prepass cost maps of the last sorted render, each local_rows x width."""
+        self._need_debug()
         own = np.zeros((self.local_rows, self.width), np.uint32)
         smoothed = np.zeros_like(own)
         u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -500,12 +523,14 @@ class Renderer:
         return own, smoothed
 
     def debug_timeline(self, threads=0):
+        self._need_debug()
         out = np.zeros((16384, 8), np.uint64)
         n = ctypes.c_int(0)
         self._check(self._lib.rtiow_debug_timeline(self._h, int(threads), out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), out.size, ctypes.byref(n)))
         return out[: n.value]
 
     def debug_ops(self, op, a, b=None, c=None):
+        self._need_debug()
         a = np.ascontiguousarray(a, self.dtype)
         b = np.ascontiguousarray(b if b is not None else a, self.dtype)
         c = np.ascontiguousarray(c if c is not None else a, self.dtype)
@@ -517,7 +542,7 @@ class Renderer:
 def debug_gather_schedule(devices, rows, width, precision=32, mode=GATHER_RCCL, fail_at=-1):
     """The exchange's schedule (rtiow_group_gather's own) run against a recorder: (list of 8-tuples, return code).
     Host only -- no GPU, no RCCL.  Record layout: csrc/rtiow_group.hip, rtiow_debug_gather_schedule."""
-    lib = load_hip_library()
+    lib = load_hip_library(debug=True)
     n = len(devices)
     cap = 16 * n + 16
     rec = (ctypes.c_int64 * (8 * cap))()

@@ -1,6 +1,7 @@
 """Build every native artefact of the package in-tree.
 
   lib/librtiow_hip.so    HIP kernels + device C-ABI (include/rtiow.h), hipcc --offload-arch=gfx950
+  lib/librtiow_hip_debug.so   the same sources with -DRTIOW_DEBUG_API: + the test hooks of include/rtiow_debug.h (tests/, study and profiling scripts only)
   lib/librtiow_host.so   host-side scene/camera/PPM C interface (include/rtiow_host.h), g++
   bin/global-float-hip-raytrace, bin/global-double-hip-raytrace   drop-in executables
   bin/ppm_diff, bin/scaled_ppm_diff, bin/csv_avg                  harness tools (when present)
@@ -58,7 +59,7 @@ def hip_build_id(extra_flags=()):
     they were measured on; bench.py uses a record only when it matches the library that is loaded."""
     import hashlib
     h = hashlib.sha256()
-    files = [os.path.join(CSRC, "rtiow_hip.hip"), os.path.join(CSRC, "rtiow_group.hip")] + hip_includes() + [os.path.join(INC, "rtiow.h")]
+    files = [os.path.join(CSRC, "rtiow_hip.hip"), os.path.join(CSRC, "rtiow_group.hip")] + hip_includes() + [os.path.join(INC, "rtiow.h"), os.path.join(INC, "rtiow_debug.h")]
     for f in files:
         h.update(os.path.relpath(f, ROOT).encode() + b"\0")
         h.update(open(f, "rb").read())
@@ -79,7 +80,7 @@ def build_stats(verbose=True):
     (lib/librtiow_hip_stats.so, -DRTIOW_PATH_STATS; used by scripts/path_stats_probe.py only)."""
     os.makedirs(LIB, exist_ok=True)
     out = os.path.join(LIB, "librtiow_hip_stats.so")
-    _run([_hipcc()] + HIP_FLAGS + ["-DRTIOW_PATH_STATS", '-DRTIOW_BUILD_ID="%s"' % hip_build_id(["-DRTIOW_PATH_STATS"]), "-o", out, os.path.join(CSRC, "rtiow_hip.hip"), os.path.join(CSRC, "rtiow_group.hip"), "-ldl"], verbose)
+    _run([_hipcc()] + HIP_FLAGS + ["-DRTIOW_PATH_STATS", "-DRTIOW_DEBUG_API", '-DRTIOW_BUILD_ID="%s"' % hip_build_id(["-DRTIOW_PATH_STATS", "-DRTIOW_DEBUG_API"]), "-o", out, os.path.join(CSRC, "rtiow_hip.hip"), os.path.join(CSRC, "rtiow_group.hip"), "-ldl"], verbose)
     return out
 
 
@@ -98,7 +99,7 @@ def build_variant(name, defines=(), csrc=None, verbose=True):
 def build(force=False, verbose=True):
     os.makedirs(LIB, exist_ok=True)
     os.makedirs(BIN, exist_ok=True)
-    headers = [os.path.join(INC, "rtiow.h"), os.path.join(INC, "rtiow_host.h")]
+    headers = [os.path.join(INC, "rtiow.h"), os.path.join(INC, "rtiow_host.h"), os.path.join(INC, "rtiow_debug.h")]
     me = os.path.abspath(__file__)
 
     hip_srcs = [os.path.join(CSRC, "rtiow_hip.hip"), os.path.join(CSRC, "rtiow_group.hip")]
@@ -106,6 +107,10 @@ def build(force=False, verbose=True):
     if force or _newer(hip_so, hip_srcs + hip_includes() + [me] + headers):
         # librccl is NOT linked: rtiow_group.hip dlopens it on first use (-ldl for old glibc)
         _run([_hipcc()] + HIP_FLAGS + ['-DRTIOW_BUILD_ID="%s"' % hip_build_id(), "-o", hip_so] + hip_srcs + ["-ldl"], verbose)
+    # the test build: the same kernels + the hooks of include/rtiow_debug.h (same flags, so the kernels are the product's; its build id names the extra define)
+    dbg_so = os.path.join(LIB, "librtiow_hip_debug.so")
+    if force or _newer(dbg_so, hip_srcs + hip_includes() + [me] + headers):
+        _run([_hipcc()] + HIP_FLAGS + ["-DRTIOW_DEBUG_API", '-DRTIOW_BUILD_ID="%s"' % hip_build_id(["-DRTIOW_DEBUG_API"]), "-o", dbg_so] + hip_srcs + ["-ldl"], verbose)
 
     host_src = os.path.join(CSRC, "host", "rtiow_host.cpp")
     host_so = os.path.join(LIB, "librtiow_host.so")

@@ -517,6 +517,7 @@ __global__ void __launch_bounds__(1024) render_prepass_kernel(const RenderParams
 template <class T, int SRC>
 __global__ void __launch_bounds__(1024) render_solo_kernel(const RenderParams<T> p) { persistent_body<T, SRC, false, true>(p); }
 
+#ifdef RTIOW_DEBUG_API       // kernels behind the test hooks of include/rtiow_debug.h
 // Elementwise arithmetic probes (tests compare these with the host bit for bit).
 template <class T>
 __global__ void debug_ops_kernel(int op, size_t n, const T* a, const T* b, const T* c, T* out) {
@@ -549,5 +550,7 @@ __global__ void __launch_bounds__(256) hit_probe_kernel(const RenderParams<T> p,
         }
     }
 }
+
+#endif  // RTIOW_DEBUG_API
 
 }  // namespace

@@ -102,6 +102,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         if (!seg_counter) { h->stats.grid_nx = h->grid.nx; h->stats.grid_nz = h->grid.nz; h->stats.grid_registered = h->grid_registered; h->stats.grid_direct = h->grid_direct; h->stats.grid_cell = h->grid.cell; }
     } else if (effective_source == RTIOW_SCENE_GRID) effective_source = RTIOW_SCENE_LDS;   // no grid for this scene: the screened loop
     if (lds > 160 * 1024) return fail_arg(h, RTIOW_E_BADARG, "scene too large for LDS staging; use RTIOW_SCENE_SCALAR");
+#ifdef RTIOW_DEBUG_API
     if (h->probe_n > 0) {                                    // rtiow_debug_hit_world: the tables are laid out, run hit_world on the caller's rays
         if (!lds_source) return fail_arg(h, RTIOW_E_STATE, "rtiow_debug_hit_world needs an LDS scene source");
         if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)hit_probe_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -111,6 +112,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         if (!seg_counter) h->stats.scene_source = effective_source;
         return 0;
     }
+#endif
     RenderFn<T> k = pick_kernel<T>(persistent, lds_source, seg_counter != nullptr);
     if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipFuncAttributes fa{};

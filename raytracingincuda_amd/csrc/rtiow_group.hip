@@ -39,6 +39,9 @@
 #include <vector>
 
 #include "rtiow.h"
+#ifdef RTIOW_DEBUG_API
+#include "rtiow_debug.h"
+#endif
 
 namespace {
 
@@ -560,6 +563,7 @@ const char* rtiow_group_transport_note(rtiow_group g) { return g ? g->transport_
 // ids: stream of rank k = 1 + k; event done[k] = 100 + k, g0 = 99; communicator of rank k = 200 + k.
 // fail_at >= 0 makes the (fail_at)-th call return an error (the schedule must stop, or -- inside an RCCL group --
 // still close the group).  Returns the number of records, or a negative RTIOW_E_* code.
+#ifdef RTIOW_DEBUG_API       // test hook (include/rtiow_debug.h): compiled into lib/librtiow_hip_debug.so only
 int rtiow_debug_gather_schedule(int n, const int* devices, const int* rows, int W, int precision, int mode, int fail_at,
                                 int64_t* records, size_t cap_records, int* schedule_rc) {
     if (n < 1 || n > 64 || !devices || !rows || W < 1 || (precision != 32 && precision != 64) || !records || !schedule_rc ||
@@ -610,5 +614,6 @@ int rtiow_debug_gather_schedule(int n, const int* devices, const int* rows, int 
     std::memcpy(records, rec.v.data(), rec.v.size() * sizeof(int64_t));
     return (int)nrec;
 }
+#endif  // RTIOW_DEBUG_API
 
 }  // extern "C"

@@ -44,6 +44,9 @@
 #include <vector>
 
 #include "rtiow.h"
+#ifdef RTIOW_DEBUG_API
+#include "rtiow_debug.h"
+#endif
 
 #include "device/xorwow.h"
 #include "device/params.h"
@@ -473,6 +476,7 @@ int rtiow_synchronize(rtiow_handle h) {
     return 0;
 }
 
+#ifdef RTIOW_DEBUG_API       // test hooks (include/rtiow_debug.h): compiled into lib/librtiow_hip_debug.so only
 int rtiow_debug_read_rng(rtiow_handle h, uint32_t* host_states, size_t count_words) {
     if (!h || !host_states) return RTIOW_E_BADARG;
     if (!h->rng_ready) return fail_arg(h, RTIOW_E_STATE, "rtiow_debug_read_rng before rtiow_init_rng");
@@ -583,5 +587,7 @@ int rtiow_debug_ops(rtiow_handle h, int op, size_t n, const void* a, const void*
     HIP_TRY(h, hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
+
+#endif  // RTIOW_DEBUG_API
 
 }  // extern "C"

@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, '.')
 import raytracingincuda_amd as rt
 W, H, S, B = 1920, 1080, 100, 50
-r = rt.Renderer(0, 32); r.set_camera(rt.camera(32, W, H, S, B)); r.set_scene(rt.build_scene(3, 32))
+r = rt.Renderer(0, 32, debug=True); r.set_camera(rt.camera(32, W, H, S, B)); r.set_scene(rt.build_scene(3, 32))
 r.init_rng(1227); r.set_schedule(2, 0)
 ms = [r.render(0) for _ in range(3)]
 seg = r.count_segments(0)
@@ -23,7 +23,7 @@ r.close()
 
 # ---- per dispatch-age class (blocks are dispatched in blockIdx order, 256 CUs x 4-wave blocks)
 def classes():
-    r = rt.Renderer(0, 32); r.set_camera(rt.camera(32, W, H, S, B)); r.set_scene(rt.build_scene(3, 32))
+    r = rt.Renderer(0, 32, debug=True); r.set_camera(rt.camera(32, W, H, S, B)); r.set_scene(rt.build_scene(3, 32))
     r.init_rng(1227); r.set_schedule(2, 0); r.render(0)
     tl = r.debug_timeline(0).astype(np.float64)
     gid = np.arange(len(tl)); ok = tl[:, 2] > 0

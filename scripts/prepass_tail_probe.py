@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracingincuda_amd as rt
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
-r = rt.Renderer(0, 32); r.set_camera(rt.camera(32, W, H, S, 50)); r.set_scene(rt.build_scene(3, 32))
+r = rt.Renderer(0, 32, debug=True); r.set_camera(rt.camera(32, W, H, S, 50)); r.set_scene(rt.build_scene(3, 32))
 r.init_rng(1227); r.set_schedule(1, 0)
 ms = [round(r.render(0), 3) for _ in range(4)]
 tl = r.debug_timeline(0).astype(np.float64)

@@ -43,7 +43,7 @@ for seed in range(n_scenes):
         rays = rays.astype(dt)
     out = {}
     for source in (rt.SCENE_GRID, rt.SCENE_LDS_EXACT):
-        with rt.Renderer(0, prec) as r:
+        with rt.Renderer(0, prec, debug=True) as r:
             r.set_camera(rt.camera(prec, 64, 64, 1, 1)); r.set_scene(sc); r.set_scene_source(source)
             out[source] = r.debug_hit_world(rays)
             if source == rt.SCENE_GRID:

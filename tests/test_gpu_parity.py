@@ -71,6 +71,11 @@ def test_native_library_is_what_runs(rt):
         assert r._lib.rtiow_abi_version() == rt.ABI_VERSION
     maps = open("/proc/self/maps").read()
     assert "librtiow_hip.so" in maps and "librtiow_host.so" in maps
+    # the product library carries no test hooks (include/rtiow_debug.h lives in librtiow_hip_debug.so only)
+    with rt.Renderer(0, 32) as r:
+        assert not hasattr(r._lib, "rtiow_debug_ops")
+        with pytest.raises(rt.RtiowError):
+            r.debug_read_rng()
 
 
 def test_device_arithmetic_is_ieee_like_the_host(rt, oracle):
@@ -81,7 +86,7 @@ def test_device_arithmetic_is_ieee_like_the_host(rt, oracle):
         a, b, c = mk(), mk(), mk()
         # include denormal results / operands
         a[:64] = np.array(np.finfo(dt).tiny, dt) * rng.uniform(0.01, 4, 64).astype(dt)
-        with rt.Renderer(0, prec) as r, np.errstate(all="ignore"):
+        with rt.Renderer(0, prec, debug=True) as r, np.errstate(all="ignore"):
             assert _same_bits(r.debug_ops(0, a, b), (a / b).astype(dt))
             assert _same_bits(r.debug_ops(1, np.abs(a)), np.sqrt(np.abs(a)).astype(dt))
             fma = np.array([np.float64(x) * np.float64(y) + np.float64(z) for x, y, z in zip(a[:2048], b[:2048], c[:2048])])
@@ -93,7 +98,7 @@ def test_device_arithmetic_is_ieee_like_the_host(rt, oracle):
     # u32 -> (0,1] float conversion, incl. the ends of the range
     xs = np.concatenate([np.array([0, 1, 2, 0x7fffffff, 0x80000000, 0xfffffffe, 0xffffffff], np.uint32),
                          rng.integers(0, 2 ** 32, 4096, dtype=np.uint64).astype(np.uint32)])
-    with rt.Renderer(0, 32) as r:
+    with rt.Renderer(0, 32, debug=True) as r:
         got = r.debug_ops(3, xs.view(np.float32))
     want = (xs.astype(np.float32) * np.float32(2.0 ** -32) + np.float32(2.0 ** -33)).astype(np.float32)
     assert _same_bits(got, want) and got.min() > 0 and got.max() <= 1.0
@@ -102,7 +107,7 @@ def test_device_arithmetic_is_ieee_like_the_host(rt, oracle):
 def test_rng_init_matches_curand_init_semantics(rt, oracle):
     # rtweekend.h:49: curand_init(1227, pixel_index, 0); also under sharding (GLOBAL index)
     for W, H, shard in [(64, 40, None), (37, 19, None), (48, 40, (1, 3, 8)), (33, 21, (2, 4, 4))]:
-        with rt.Renderer(0, 32) as r:
+        with rt.Renderer(0, 32, debug=True) as r:
             r.set_camera(rt.camera(32, W, H, 1, 1))
             if shard:
                 r.set_shard(*shard)
@@ -111,7 +116,7 @@ def test_rng_init_matches_curand_init_semantics(rt, oracle):
             got = r.debug_read_rng()
         seqs = (rows[:, None].astype(np.int64) * W + np.arange(W)[None, :]).ravel()
         assert np.array_equal(got, oracle.xorwow_states(1227, seqs))
-    with rt.Renderer(0, 32) as r:          # another seed, high subsequence bits
+    with rt.Renderer(0, 32, debug=True) as r:          # another seed, high subsequence bits
         r.set_camera(rt.camera(32, 2048, 1100, 1, 1))
         r.set_shard(7, 8, 8)
         r.init_rng(0x1234567890ABCDEF)
@@ -621,7 +626,7 @@ def test_hit_world_ray_by_ray_grid_vs_exact(rt, oracle, prec, scene_id):
         rays = rays.astype(dt)
     out = {}
     for source in (rt.SCENE_GRID, rt.SCENE_LDS_EXACT, rt.SCENE_LDS):
-        with rt.Renderer(0, prec) as r:
+        with rt.Renderer(0, prec, debug=True) as r:
             r.set_camera(rt.camera(prec, 64, 64, 1, 1)); r.set_scene(sc); r.set_scene_source(source)
             out[source] = r.debug_hit_world(rays)
             if source == rt.SCENE_GRID:
@@ -786,7 +791,7 @@ def test_solo_waves_leave_the_image_alone(rt, oracle, prec, scene_id, W, H, S, B
 def test_sort_key_is_the_neighbourhood_mean_of_the_prepass_cost(rt, W, H, shard):
     """cost_smooth_kernel (LDS tiles) against the definition: the mean of the prepass cost over the 13 x 13 window
     clipped to the image and to the pixel's own row strip, in quarter segments, rounded to nearest."""
-    with rt.Renderer(0, 32) as r:
+    with rt.Renderer(0, 32, debug=True) as r:
         r.set_camera(rt.camera(32, W, H, 32, 50)); r.set_scene(rt.build_scene(3, 32))
         strip = H                                            # one rank: its strips are adjacent, the window crosses them
         if shard:

@@ -17,7 +17,7 @@ import pytest
 
 
 def _plan(native, cr, centre=None):
-    lib = native.load_hip_library()
+    lib = native.load_hip_library(debug=True)       # the plan is a test hook (include/rtiow_debug.h): the test build exports it
     cr = np.ascontiguousarray(cr, np.float64)
     n = len(cr)
     if centre is None:                                    # the library's recentring point: centroid of the spheres with r < 100

@@ -21,8 +21,10 @@ def test_c_abi_exports_every_declared_symbol(native):
     from raytracingincuda_amd import api
     paths = native.lib_paths()
     hip_decl, host_decl = _declared("rtiow.h"), _declared("rtiow_host.h")
+    dbg_decl = [d for d in _declared("rtiow_debug.h") if d.startswith("rtiow_debug_") and d not in ("rtiow_debug_region_cycles", "rtiow_debug_path_stats")]   # those two: instrumented builds only
     assert sorted(api.HIP_SYMBOLS) == hip_decl
     assert sorted(api.HOST_SYMBOLS) == host_decl
+    assert sorted(api.DEBUG_SYMBOLS) == dbg_decl and not [d for d in hip_decl if "debug" in d]
     # dlopen both (no compute call: there is no GPU here) and resolve each symbol
     hip = ctypes.CDLL(paths["hip"])
     host = ctypes.CDLL(paths["host"])
@@ -35,6 +37,11 @@ def test_c_abi_exports_every_declared_symbol(native):
     syms = subprocess.run(["nm", "-D", "--defined-only", paths["hip"]], capture_output=True, text=True, check=True).stdout
     for s in hip_decl:
         assert re.search(r"\bT %s\b" % s, syms), s
+    # test hooks ship in the test build only: the product exports none, the debug build exports the product's ABI plus every hook
+    assert "rtiow_debug_" not in syms
+    dsyms = subprocess.run(["nm", "-D", "--defined-only", paths["hip_debug"]], capture_output=True, text=True, check=True).stdout
+    for s in hip_decl + dbg_decl:
+        assert re.search(r"\bT %s\b" % s, dsyms), s
 
 
 def test_no_gpu_means_loud_failure_not_fallback(native):
@@ -188,7 +195,7 @@ def test_committed_jump_constant_equals_the_matrix_power(native):
     """xorwow_jump67.inc (A^(2^67), used to skip 67 of the 98 squarings per process) against the same 32
     jump matrices derived from the one-step matrix A: host arithmetic of librtiow_hip.so, no GPU needed."""
     import ctypes
-    lib = ctypes.CDLL(native.lib_paths()["hip"])
+    lib = ctypes.CDLL(native.lib_paths()["hip_debug"])
     lib.rtiow_debug_jump_matrices.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t, ctypes.c_int]
     n = 32 * 160 * 5
     fast, scratch = (ctypes.c_uint32 * n)(), (ctypes.c_uint32 * n)()
