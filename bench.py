@@ -85,7 +85,7 @@ def parse():
     ap.add_argument("--schedule", default="sorted", choices=("sorted", "persistent", "static"))
     ap.add_argument("--strip_rows", type=int, default=0, help="rows per interleaved strip; 0 = 8 for N <= 2, 2 for N >= 4 (profiles/r01_strip_rows_sweep.txt)")
     ap.add_argument("--devices", default="", help="without a launcher: the device of every rank, e.g. 0,1,2,3 (default 0..N-1); a device may repeat")
-    ap.add_argument("--gather", default="auto", choices=("auto", "rccl", "peer"), help="transport of the in-library group (without a launcher, N > 1)")
+    ap.add_argument("--gather", default="auto", choices=("auto", "rccl", "peer", "host"), help="transport of the in-library group (without a launcher, N > 1); auto falls back rccl -> peer -> host at gather time")
     ap.add_argument("--pmc", default="auto", choices=("auto", "live", "committed", "off"),
                     help="where roofline.frac's counters come from: rocprofv3 --pmc passes run now (live), the committed record if it matches "
                          "the loaded build (committed), neither (off); auto = live at N = 1, falling back to committed")
@@ -390,7 +390,7 @@ def run_group(args, json_fd):
     W, H, S, B = args.width, args.height, args.samples, args.bounces
     scene = rt.build_scene(args.scene_id, prec)
     cam = rt.camera(prec, W, H, S, B)
-    gather = {"auto": rt.GATHER_AUTO, "rccl": rt.GATHER_RCCL, "peer": rt.GATHER_PEER}[args.gather]
+    gather = {"auto": rt.GATHER_AUTO, "rccl": rt.GATHER_RCCL, "peer": rt.GATHER_PEER, "host": rt.GATHER_HOST}[args.gather]
     g = rt.RendererGroup(N, prec, args.strip_rows, gather, devices)      # raises when the node has fewer GPUs or the HIP library is missing
     g.set_camera(cam)
     g.set_scene(scene)
@@ -427,7 +427,8 @@ def run_group(args, json_fd):
            "segments_main0": segments_main0, "segments_total": float(sum(segments)), "kernel_mean_max": float(np.mean(kernel_ms)),
            "kernel_ms_per_rank": [round(float(x), 4) for x in np.mean(np.array(per_rank), axis=0)],
            "gather_ms_per_rank": None, "gather_ms": float(np.mean(gather_ms)),
-           "gather_transport": {rt.GATHER_RCCL: "rccl %d (ncclSend/ncclRecv to device 0)" % gs["rccl_version"], rt.GATHER_PEER: "peer copies" + (": " + gs["transport_note"] if gs["transport_note"] else "")}.get(gs["gather_mode"], "none"),
+           "gather_transport": {rt.GATHER_RCCL: "rccl %d (ncclSend/ncclRecv to device 0)" % gs["rccl_version"], rt.GATHER_PEER: "peer copies" + (": " + gs["transport_note"] if gs["transport_note"] else ""),
+                               rt.GATHER_HOST: "host-staged copies" + (": " + gs["transport_note"] if gs["transport_note"] else "")}.get(gs["gather_mode"], "none"),
            "floor_ms": floor, "chain_max": max(chains), "trip_us": trip_us, "trip_segments": trip_segments,
            "sharding": "interleaved %d-row strips over %d ranks, one exchange to rank 0 inside the step" % (args.strip_rows, N),
            "backend": "rtiow_group (in-library RCCL / peer copies)", "host": "one process, devices %s" % ",".join(str(d) for d in devices),

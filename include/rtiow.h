@@ -236,6 +236,10 @@ int rtiow_device(rtiow_handle h, int* device);
 #define RTIOW_GATHER_AUTO 0   /* RCCL if it loads and initialises, else peer copies */
 #define RTIOW_GATHER_RCCL 1   /* RCCL or fail                                        */
 #define RTIOW_GATHER_PEER 2   /* hipMemcpyPeerAsync per device                       */
+#define RTIOW_GATHER_HOST 3   /* every strip through a host bounce buffer (blocking copies): the last resort of RTIOW_GATHER_AUTO when a
+                               * transport fails AT GATHER TIME (first ncclGroupEnd / send / recv, first peer copy): the group then falls back
+                               * RCCL -> peer copies -> host inside the same call, drains the devices in between, and says so in
+                               * rtiow_group_transport_note / rtiow_group_stats.gather_mode.  May also be requested outright. */
 #define RTIOW_GROUP_MAX_STATS 16
 
 typedef struct rtiow_group_s* rtiow_group;

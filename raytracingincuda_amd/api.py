@@ -17,13 +17,14 @@ raise.  (The CPU oracle lives in oracle/ and is test infrastructure only.)
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 SCENE_LDS, SCENE_SCALAR, SCENE_LDS_EXACT, SCENE_GRID = 0, 1, 2, 3
 SCHED_STATIC, SCHED_PERSISTENT, SCHED_SORTED = 0, 1, 2
-GATHER_AUTO, GATHER_RCCL, GATHER_PEER = 0, 1, 2
+GATHER_AUTO, GATHER_RCCL, GATHER_PEER, GATHER_HOST = 0, 1, 2, 3
 GROUP_MAX_STATS = 16
 ABI_VERSION = 5          # include/rtiow.h RTIOW_ABI_VERSION
 
@@ -539,12 +540,16 @@ class Renderer:
         return out
 
 
-def debug_gather_schedule(devices, rows, width, precision=32, mode=GATHER_RCCL, fail_at=-1):
+def debug_gather_schedule(devices, rows, width, precision=32, mode=GATHER_RCCL, fail_at=-1, fallback=False):
     """The exchange's schedule (rtiow_group_gather's own) run against a recorder: (list of 8-tuples, return code).
-    Host only -- no GPU, no RCCL.  Record layout: csrc/rtiow_group.hip, rtiow_debug_gather_schedule."""
+    Host only -- no GPU, no RCCL.  Record layout: csrc/rtiow_group.hip, rtiow_debug_gather_schedule.
+    fallback=True: with RTIOW_GATHER_AUTO's chain (a transport that fails at gather time -> drain -> the next one, from the top);
+    the last record is then (12, -1, transport that carried the image, ...)."""
     lib = load_hip_library(debug=True)
     n = len(devices)
-    cap = 16 * n + 16
+    cap = 3 * (16 * n + 16) + 8
+    if fallback:
+        mode = int(mode) | 0x100
     rec = (ctypes.c_int64 * (8 * cap))()
     rc = ctypes.c_int(0)
     got = lib.rtiow_debug_gather_schedule(n, (ctypes.c_int * n)(*devices), (ctypes.c_int * n)(*rows), int(width), int(precision), int(mode), int(fail_at),
@@ -557,9 +562,28 @@ def debug_gather_schedule(devices, rows, width, precision=32, mode=GATHER_RCCL, 
 class RendererGroup:
     """Several GPUs of one node driven from this process (rtiow_group_*, include/rtiow.h): interleaved
     row strips, one exchange to device 0 after the render (RCCL, or peer copies), de-interleaved there.
-    `devices` may repeat a device: the ranks then share it (how the N-rank logic is tested on one GPU)."""
+    `devices` may repeat a device: the ranks then share it (how the N-rank logic is tested on one GPU).
 
-    def __init__(self, ngpus=1, precision=32, strip_rows=8, gather=GATHER_AUTO, devices=None):
+    STDOUT: RCCL prints a version banner ("RCCL version : ...") on the process's stdout when its first communicator is created, i.e.
+    inside this constructor's rtiow_group_create on distinct devices.  The library does not touch file descriptors; a
+    caller whose stdout is data passes quiet_stdout=True, which points fd 1 at stderr for the duration of the constructor (process-wide:
+    only for callers with no other thread writing to stdout), or does the same around the call itself (bench.py, the executables)."""
+
+    def __init__(self, ngpus=1, precision=32, strip_rows=8, gather=GATHER_AUTO, devices=None, quiet_stdout=False):
+        saved = -1
+        if quiet_stdout:
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+        try:
+            self._create(ngpus, precision, strip_rows, gather, devices)
+        finally:
+            if saved >= 0:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
+
+    def _create(self, ngpus, precision, strip_rows, gather, devices):
         self._lib = load_hip_library()
         self.precision, self.dtype, self.ngpus = precision, _dtype(precision), int(ngpus)
         self._g = ctypes.c_void_p()

@@ -108,6 +108,7 @@ Options parse(int argc, char** argv) {
             if (value == "auto") o.gather = RTIOW_GATHER_AUTO;
             else if (value == "rccl") o.gather = RTIOW_GATHER_RCCL;
             else if (value == "peer") o.gather = RTIOW_GATHER_PEER;
+            else if (value == "host") o.gather = RTIOW_GATHER_HOST;
             else parse_abort("Argument '" + value + "' failed to parse");
             continue;
         }
@@ -249,7 +250,7 @@ int main_multi_gpu(const Options& opt) {
                      "\"wall_ms\": {\"group_create\": %.3f, \"setup\": %.3f, \"rng_init\": %.3f, \"render\": %.3f, \"gather_and_readback\": %.3f, \"ppm_write\": %.3f, \"end_to_end\": %.3f}, "
                      "\"end_to_end_excludes\": \"group_create\"}\n",
                      render_ms > 0 ? rays / render_ms / 1e3 : 0.0, (double)render_ms, n, strip_rows, per.c_str(),
-                     gs.gather_mode == RTIOW_GATHER_RCCL ? "rccl" : "peer", gs.rccl_version, gs.gather_ms, (unsigned long long)gs.gather_bytes, note.c_str(),
+                     gs.gather_mode == RTIOW_GATHER_RCCL ? "rccl" : (gs.gather_mode == RTIOW_GATHER_HOST ? "host" : "peer"), gs.rccl_version, gs.gather_ms, (unsigned long long)gs.gather_bytes, note.c_str(),
                      gs.peer_links, gs.create_ms, t_setup, t_rng, t_render, t_read, t_write, e2e_ms);
     }
     return 0;

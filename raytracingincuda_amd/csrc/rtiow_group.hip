@@ -35,6 +35,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -108,6 +109,10 @@ struct GatherBackend {
     int (*group_end)(void* self);
     int (*send)(void* self, const void* buf, size_t count, int fp64, int peer, void* comm, hipStream_t s);
     int (*recv)(void* self, void* buf, size_t count, int fp64, int peer, void* comm, hipStream_t s);
+    // host mode and the fallback between transports
+    int (*stream_sync)(void* self, hipStream_t s);
+    int (*copy_via_host)(void* self, void* dst, int dst_dev, hipStream_t dst_stream, const void* src, int src_dev, size_t bytes);   // blocking D2H into a bounce buffer, H2D on dst_stream, awaited
+    int (*drain)(void* self, int ndev, const int* dev);      // after a failing transport: every device idle, sticky errors cleared (never fails the chain)
 };
 
 struct GatherInputs {
@@ -151,6 +156,15 @@ int run_gather_schedule(const GatherInputs& in, const GatherBackend& be, const c
         const int r2 = be.group_end(be.self);      // always closed, also after a failing call inside the group
         if (r == 0 && r2 != 0) { r = r2; failed = "ncclGroupEnd"; }
         if (r != 0) { where = failed; return r; }
+    } else if (in.mode == RTIOW_GATHER_HOST) {
+        // last resort: blocking copies through the host, rank by rank (every rank's render awaited first; stream 0 holds every block at the end)
+        for (int k = 0; k < in.n; ++k) {
+            const size_t bytes = (size_t)in.rows[k] * in.W * 3 * es;
+            if (bytes == 0) continue;
+            GB(be.set_device(be.self, in.dev[k]), "hipSetDevice");
+            GB(be.stream_sync(be.self, in.stream[k]), "hipStreamSynchronize");
+            GB(be.copy_via_host(be.self, (char*)in.staged + in.offsets[k] * es, in.dev[0], s0, in.fb[k], in.dev[k], bytes), "hipMemcpy (host-staged)");
+        }
     } else {
         for (int k = 0; k < in.n; ++k) {
             const size_t bytes = (size_t)in.rows[k] * in.W * 3 * es;
@@ -174,8 +188,29 @@ int run_gather_schedule(const GatherInputs& in, const GatherBackend& be, const c
     return 0;
 }
 
+// A transport that fails AT GATHER TIME (the first ncclGroupEnd / send / recv between distinct devices, the first peer copy) must not end
+// the frame when another one can carry it: with `fallback` the exchange is tried RCCL -> peer copies -> host-staged copies, in this
+// process, each attempt from the top of the schedule after the devices have been drained.  `attempts` collects what failed and why
+// (rtiow_group_transport_note); in.mode is left at the transport that carried the image.  Without `fallback` (an explicitly requested
+// transport) the first failure is the result.
+int run_gather_with_fallback(GatherInputs& in, const GatherBackend& be, bool fallback, const char*& where, std::string& attempts,
+                             const std::function<std::string(int, const char*)>& describe) {
+    for (;;) {
+        where = "";
+        const int rc = run_gather_schedule(in, be, where);
+        if (rc == 0) return 0;
+        if (!fallback || in.mode == RTIOW_GATHER_HOST) return rc;
+        const int next = in.mode == RTIOW_GATHER_RCCL ? RTIOW_GATHER_PEER : RTIOW_GATHER_HOST;
+        if (!attempts.empty()) attempts += "; ";
+        attempts += std::string(in.mode == RTIOW_GATHER_RCCL ? "RCCL" : "peer copies") + " failed at gather time in " + where + " (" + describe(rc, where) + "), fell back to " +
+                    (next == RTIOW_GATHER_PEER ? "peer copies" : "host-staged copies");
+        (void)be.drain(be.self, in.n, in.dev);
+        in.mode = next;
+    }
+}
+
 // The real table.  self = the group's RcclApi (null entries are never reached in peer mode).
-struct HipBackendSelf { RcclApi* rccl; int last_nccl; };
+struct HipBackendSelf { RcclApi* rccl; int last_nccl; std::vector<unsigned char>* bounce; };
 GatherBackend hip_backend(HipBackendSelf* self) {
     GatherBackend b;
     b.self = self;
@@ -190,6 +225,20 @@ GatherBackend hip_backend(HipBackendSelf* self) {
         auto* h = (HipBackendSelf*)p; return h->last_nccl = (int)h->rccl->Send(buf, count, fp64 ? ncclDouble : ncclFloat, peer, (ncclComm_t)comm, s); };
     b.recv = [](void* p, void* buf, size_t count, int fp64, int peer, void* comm, hipStream_t s) {
         auto* h = (HipBackendSelf*)p; return h->last_nccl = (int)h->rccl->Recv(buf, count, fp64 ? ncclDouble : ncclFloat, peer, (ncclComm_t)comm, s); };
+    b.stream_sync = [](void*, hipStream_t s) { return (int)hipStreamSynchronize(s); };
+    b.copy_via_host = [](void* p, void* dst, int dst_dev, hipStream_t dst_stream, const void* src, int src_dev, size_t bytes) {
+        auto* h = (HipBackendSelf*)p;
+        if (h->bounce->size() < bytes) h->bounce->resize(bytes);
+        hipError_t e = hipSetDevice(src_dev);
+        if (e == hipSuccess) e = hipMemcpy(h->bounce->data(), src, bytes, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipSetDevice(dst_dev);
+        if (e == hipSuccess) e = hipMemcpyAsync(dst, h->bounce->data(), bytes, hipMemcpyHostToDevice, dst_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(dst_stream);      // the bounce buffer is reused by the next rank
+        return (int)e; };
+    b.drain = [](void*, int ndev, const int* dev) {
+        for (int k = 0; k < ndev; ++k) { if (hipSetDevice(dev[k]) == hipSuccess) (void)hipDeviceSynchronize(); (void)hipGetLastError(); }
+        (void)hipSetDevice(dev[0]); (void)hipGetLastError();
+        return 0; };
     return b;
 }
 
@@ -209,7 +258,8 @@ struct rtiow_group_s {
     RcclApi rccl;
     std::vector<ncclComm_t> comms;
     int rccl_version = 0;
-    std::string transport_note;                 // why auto mode fell back, if it did
+    std::string transport_note;                 // why auto mode fell back, if it did (at creation / first gather, or at gather time)
+    std::vector<unsigned char> bounce;          // RTIOW_GATHER_HOST: the host bounce buffer
     int peer_links = 0;                         // peer mode: ranks whose device has direct access to device 0 enabled
     double create_ms = 0;                       // wall time of rtiow_group_create (contexts, streams, communicator)
     // device 0 buffers
@@ -266,12 +316,15 @@ void enable_peer_access_to_root(rtiow_group_s* g) {
         if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) ++g->peer_links;
         (void)hipGetLastError();
     }
+    (void)hipSetDevice(g->dev[0]);              // leave device 0 current, as every caller finds it
+    (void)hipGetLastError();
 }
 
 // Decide the transport once.  AUTO prefers RCCL and records why it did not get it.
 int resolve_transport(rtiow_group_s* g) {
     if (g->gather_mode) return 0;
     if (g->gather_requested == RTIOW_GATHER_PEER) { g->gather_mode = RTIOW_GATHER_PEER; enable_peer_access_to_root(g); return 0; }
+    if (g->gather_requested == RTIOW_GATHER_HOST) { g->gather_mode = RTIOW_GATHER_HOST; return 0; }
     std::string why;
     bool ok = true;
     if (!distinct_devices(g)) { ok = false; why = "the group maps several ranks to one device (ncclCommInitAll needs distinct devices)"; }
@@ -340,7 +393,7 @@ int rtiow_group_create(int ngpus, const int* devices, int precision, int strip_r
     if (!out) return RTIOW_E_BADARG;
     *out = nullptr;
     if (ngpus < 1 || ngpus > 64 || (precision != 32 && precision != 64) || strip_rows < 1 ||
-        (gather != RTIOW_GATHER_AUTO && gather != RTIOW_GATHER_RCCL && gather != RTIOW_GATHER_PEER)) return RTIOW_E_BADARG;
+        (gather != RTIOW_GATHER_AUTO && gather != RTIOW_GATHER_RCCL && gather != RTIOW_GATHER_PEER && gather != RTIOW_GATHER_HOST)) return RTIOW_E_BADARG;
     rtiow_group_s* g = new (std::nothrow) rtiow_group_s();
     if (!g) return RTIOW_E_NOMEM;
     const auto t_create = std::chrono::steady_clock::now();
@@ -494,9 +547,18 @@ int rtiow_group_gather(rtiow_group g) {
         in.n = g->n; in.mode = g->gather_mode; in.W = g->W; in.fp64 = g->precision == 64;
         in.dev = g->dev.data(); in.rows = g->rows.data(); in.offsets = g->host_offsets.data(); in.fb = fb.data(); in.staged = g->staged;
         in.stream = g->stream.data(); in.done = g->done.data(); in.g0 = g->g0; in.comms = comms.data();
-        HipBackendSelf self{&g->rccl, 0};
+        HipBackendSelf self{&g->rccl, 0, &g->bounce};
         const char* where = "";
-        const int src = run_gather_schedule(in, hip_backend(&self), where);
+        std::string attempts;
+        auto describe = [g](int rc, const char* w) { return std::string(w[0] == 'n' ? g->rccl.GetErrorString((ncclResult_t)rc) : hipGetErrorString((hipError_t)rc)); };
+        const int mode_before = in.mode;
+        const int src = run_gather_with_fallback(in, hip_backend(&self), g->gather_requested == RTIOW_GATHER_AUTO, where, attempts, describe);
+        if (in.mode != mode_before) {
+            // the transport changed at gather time: it stays changed (peer access enabled for peer copies), and the note says why
+            g->gather_mode = in.mode;
+            if (in.mode == RTIOW_GATHER_PEER) enable_peer_access_to_root(g);
+            g->transport_note = g->transport_note.empty() ? attempts : g->transport_note + "; " + attempts;
+        }
         if (src) {
             if (where[0] == 'n') return gfail(g, RTIOW_E_STATE, std::string("RCCL gather failed in ") + where + ": " + g->rccl.GetErrorString((ncclResult_t)src));
             return gfail(g, src, std::string("HIP_SAFE_CALL: ") + hipGetErrorString((hipError_t)src) + " in the exchange (" + where + ")");
@@ -567,7 +629,10 @@ const char* rtiow_group_transport_note(rtiow_group g) { return g ? g->transport_
 int rtiow_debug_gather_schedule(int n, const int* devices, const int* rows, int W, int precision, int mode, int fail_at,
                                 int64_t* records, size_t cap_records, int* schedule_rc) {
     if (n < 1 || n > 64 || !devices || !rows || W < 1 || (precision != 32 && precision != 64) || !records || !schedule_rc ||
-        (mode != RTIOW_GATHER_RCCL && mode != RTIOW_GATHER_PEER)) return RTIOW_E_BADARG;
+        ((mode & 0xff) != RTIOW_GATHER_RCCL && (mode & 0xff) != RTIOW_GATHER_PEER && (mode & 0xff) != RTIOW_GATHER_HOST) || (mode & ~0x1ff)) return RTIOW_E_BADARG;
+    // mode | 0x100: with the fallback chain of RTIOW_GATHER_AUTO (run_gather_with_fallback); the last record is then {12, -, transport that carried the image}
+    const bool fallback = (mode & 0x100) != 0;
+    mode &= 0xff;
     struct Rec { std::vector<int64_t> v; int device = -1; int calls = 0, fail_at = -1; char* staged; std::vector<void*> fb;
                  int hit() { return calls++ == fail_at ? 999 : 0; }
                  int64_t rank_of(const void* p) const { for (size_t k = 0; k < fb.size(); ++k) if (fb[k] == p) return (int64_t)k; return -1; }
@@ -601,13 +666,24 @@ int rtiow_debug_gather_schedule(int n, const int* devices, const int* rows, int 
         auto* r = (Rec*)p; r->put(8, r->rank_of(buf), (int64_t)count, fp64, peer, (int64_t)(uintptr_t)comm, (int64_t)(uintptr_t)s); return r->hit(); };
     b.recv = [](void* p, void* buf, size_t count, int fp64, int peer, void* comm, hipStream_t s) {
         auto* r = (Rec*)p; r->put(9, (char*)buf - r->staged, (int64_t)count, fp64, peer, (int64_t)(uintptr_t)comm, (int64_t)(uintptr_t)s); return r->hit(); };
+    b.stream_sync = [](void* p, hipStream_t s) { auto* r = (Rec*)p; r->put(10, (int64_t)(uintptr_t)s); return r->hit(); };
+    b.copy_via_host = [](void* p, void* dst, int dd, hipStream_t ds, const void* src, int sd, size_t bytes) {
+        auto* r = (Rec*)p; r->put(11, (char*)dst - r->staged, r->rank_of(src), (int64_t)bytes, (int64_t)(uintptr_t)ds, dd, sd); return r->hit(); };
+    b.drain = [](void* p, int ndev, const int*) { auto* r = (Rec*)p; r->put(13, ndev); return 0; };      // never fails, not counted by fail_at
     (void)id;
     GatherInputs in;
     in.n = n; in.mode = mode; in.W = W; in.fp64 = precision == 64;
     in.dev = devices; in.rows = rows; in.offsets = offsets.data(); in.fb = rec.fb.data(); in.staged = rec.staged;
     in.stream = stream.data(); in.done = done.data(); in.g0 = (hipEvent_t)(uintptr_t)99; in.comms = comms.data();
     const char* where = "";
-    *schedule_rc = run_gather_schedule(in, b, where);
+    if (fallback) {
+        std::string attempts;
+        *schedule_rc = run_gather_with_fallback(in, b, true, where, attempts, [](int, const char*) { return std::string("injected"); });
+        rec.device = -1;
+        rec.put(12, in.mode, (int64_t)attempts.size());
+    } else {
+        *schedule_rc = run_gather_schedule(in, b, where);
+    }
     (void)es;
     const size_t nrec = rec.v.size() / 8;
     if (nrec > cap_records) return RTIOW_E_BADARG;

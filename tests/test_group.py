@@ -146,6 +146,41 @@ def test_group_over_distinct_devices(native):
             assert st["gather_mode"] == gather and st["gather_bytes"] == W * H * 3 * (prec // 8) and st["gather_ms"] > 0
             if gather == rt.GATHER_PEER:
                 assert 0 <= st["peer_links"] <= n - 1
+    # ... and the way the driver's scaling run starts it when it uses no launcher: `python3 bench.py --gpus N` drives the N devices from one
+    # process (RTIOW_GATHER_AUTO: RCCL, falling back peer -> host at gather time); ONE contract line, whole-job value, per-rank kernel times
+    import json, subprocess, sys
+    from tests.conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1", "--width", "640", "--height", "360",
+                        "--samples", "32", "--bounces", "25", "--no-scaling-probe"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["scaling"] == "strong" and d["unit"] == "Mrays/s" and d["value"] > 0
+    assert abs(d["value"] - 640 * 360 * 32 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]
+    sd = d["scaling_detail"]
+    assert len(sd["kernel_ms_per_rank"]) == n and sd["gather_ms"] > 0 and sd["gather_bytes_total"] == 640 * 360 * 12
+    assert sd["gather_transport"].startswith(("rccl", "peer copies", "host-staged copies"))
+
+
+@pytest.mark.gpu
+def test_host_staged_gather_and_fallback_note(native):
+    """RTIOW_GATHER_HOST (the end of the fallback chain) on what a one-GPU box can run -- ranks sharing device 0 -- gives the single-handle image
+    bit for bit and reports itself; rtiow_group_create rejects an unknown transport."""
+    rt = native
+    prec, W, H, S, B = 32, 200, 101, 4, 25
+    with rt.Renderer(0, prec) as r:
+        r.set_camera(rt.camera(prec, W, H, S, B)); r.set_scene(rt.build_scene(3, prec)); r.init_rng(1227)
+        r.render(0)
+        want = r.read_framebuffer()
+    with rt.RendererGroup(3, prec, 2, rt.GATHER_HOST, [0, 0, 0]) as g:
+        g.set_camera(rt.camera(prec, W, H, S, B)); g.set_scene(rt.build_scene(3, prec)); g.init_rng(1227)
+        g.render(0)
+        got = g.read_framebuffer()
+        st = g.stats()
+    assert _same_bits(got, want) and st["gather_mode"] == rt.GATHER_HOST and st["gather_bytes"] == W * H * 12
+    with pytest.raises(rt.RtiowError):
+        rt.RendererGroup(2, prec, 2, 7, [0, 0])
 
 
 @pytest.mark.gpu

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 SET_DEVICE, WAIT, RECORD, COPY, COPY_PEER, GROUP_START, GROUP_END, SEND, RECV = range(1, 10)
+STREAM_SYNC, COPY_VIA_HOST, CARRIED_BY, DRAIN = 10, 11, 12, 13
 G0 = 99
 
 
@@ -165,6 +166,60 @@ def test_a_failing_call_stops_the_schedule_and_closes_the_group(native):
     for fail_at in range(len(full)):
         rec, rc = native.debug_gather_schedule([0, 1, 0], [8, 8, 8], W, 32, native.GATHER_PEER, fail_at)
         assert rc == 999 and [r[0] for r in rec] == [r[0] for r in full][:fail_at + 1]
+
+
+def test_host_staged_schedule(native):
+    """RTIOW_GATHER_HOST, the last resort: per rank with rows -- its device current, its stream awaited, one blocking copy through the host
+    into its block of the staging buffer on device 0's stream; the blocks tile the buffer."""
+    devices, rows, W = [0, 1, 2, 1], [8, 6, 0, 2], 10
+    rec, rc = native.debug_gather_schedule(devices, rows, W, 64, native.GATHER_HOST)
+    assert rc == 0
+    copies = [r for r in rec if r[0] == COPY_VIA_HOST]
+    assert [c[3] for c in copies] == [0, 1, 3]                                   # ranks with rows, in order
+    off = 0
+    for c, k in zip(copies, (0, 1, 3)):
+        assert c[2] == off * 8 and c[4] == rows[k] * W * 3 * 8 and c[5] == stream(0) and c[6] == devices[0] and c[7] == devices[k]
+        i = rec.index(c)
+        assert rec[i - 1][0] == STREAM_SYNC and rec[i - 1][2] == stream(k) and rec[i - 2][0] == SET_DEVICE and rec[i - 2][2] == devices[k]
+        off += rows[k] * W * 3
+    assert rec[-1][0] == SET_DEVICE and rec[-1][2] == devices[0]
+
+
+def test_fallback_chain_at_gather_time(native):
+    """VERDICT r03 #6a: the first ncclGroupEnd / send / recv between distinct devices has never run; if it fails the frame must still arrive.
+    With RTIOW_GATHER_AUTO's chain a failing transport is followed -- in the same call -- by a drain of every device and the NEXT transport
+    from the top of its schedule: RCCL -> peer copies -> host-staged copies.  Pinned here against the recording call table, for a failure at
+    every call of every transport."""
+    devices, rows, W = [0, 1, 2, 3], [8, 8, 8, 8], 32
+    rccl, _ = native.debug_gather_schedule(devices, rows, W, 32, native.GATHER_RCCL)
+    peer, _ = native.debug_gather_schedule(devices, rows, W, 32, native.GATHER_PEER)
+    host, _ = native.debug_gather_schedule(devices, rows, W, 32, native.GATHER_HOST)
+    ops = lambda recs: [r[0] for r in recs]
+    # nothing fails: the chain is the plain schedule + the closing record
+    rec, rc = native.debug_gather_schedule(devices, rows, W, 32, native.GATHER_RCCL, fallback=True)
+    assert rc == 0 and ops(rec[:-1]) == ops(rccl) and rec[-1][0] == CARRIED_BY and rec[-1][2] == native.GATHER_RCCL
+    # RCCL fails at its k-th call: the group is closed if it was open, the devices drained, peer copies run in full
+    for fail_at in range(len(rccl)):
+        rec, rc = native.debug_gather_schedule(devices, rows, W, 32, native.GATHER_RCCL, fail_at, fallback=True)
+        o = ops(rec)
+        i = o.index(DRAIN)
+        assert rc == 0 and o.count(DRAIN) == 1 and rec[i][2] == len(devices)
+        head = ops(rccl)[:fail_at + 1] + ([GROUP_END] if ops(rccl)[fail_at] in (GROUP_START, SEND, RECV) else [])
+        assert o[:i] == head and o[i + 1:-1] == ops(peer)
+        assert [r[2:] for r in rec[i + 1:-1]] == [r[2:] for r in peer]             # same arguments as a plain peer gather
+        assert rec[-1][0] == CARRIED_BY and rec[-1][2] == native.GATHER_PEER and rec[-1][3] > 0   # and a note that says why
+    # peer copies fail at their k-th call: host-staged copies carry the image
+    for fail_at in range(len(peer)):
+        rec, rc = native.debug_gather_schedule(devices, rows, W, 32, native.GATHER_PEER, fail_at, fallback=True)
+        o = ops(rec)
+        i = o.index(DRAIN)
+        assert rc == 0 and o[:i] == ops(peer)[:fail_at + 1] and o[i + 1:-1] == ops(host) and rec[-1][2] == native.GATHER_HOST
+    # the host path is the end of the chain: its failure is the call's failure
+    rec, rc = native.debug_gather_schedule(devices, rows, W, 32, native.GATHER_HOST, 4, fallback=True)
+    assert rc == 999 and DRAIN not in ops(rec) and rec[-1][2] == native.GATHER_HOST
+    # without the chain (a transport requested outright) the first failure is the result (test_a_failing_call_stops_the_schedule_...)
+    rec, rc = native.debug_gather_schedule(devices, rows, W, 32, native.GATHER_RCCL, 3)
+    assert rc == 999 and DRAIN not in ops(rec)
 
 
 def test_schedule_hook_rejects_bad_arguments(native):

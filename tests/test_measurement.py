@@ -132,3 +132,21 @@ def test_committed_records_name_their_build(native):
     assert recs and all(len(r.get("build_id", "")) >= 8 and r["counters"].get("main", {}).get("SQ_INSTS_VALU", 0) > 0 for r in recs.values())
     current = [k for k, r in recs.items() if r["build_id"] == native.build_id()]
     print("records of the current build:", current or "none (bench.py --pmc committed prints null; the default live passes do not need them)")
+
+
+def test_scaling_table_reads_driver_records(tmp_path):
+    """scripts/scaling_table.py: SCALE_rNN.json (contract lines nested anywhere, or raw lines) -> ms, speed-up, efficiency, against floor_ms."""
+    import json, subprocess, sys
+    from tests.conftest import ROOT
+    lines = [{"n_gpus": n, "ms_per_step": ms, "value": 1920 * 1080 * 100 / ms / 1e3,
+              "scaling_detail": {"floor_ms": 4.0, "kernel_ms_per_rank": [ms - 0.2] * n, "gather_ms": 0.1, "gather_transport": "rccl"}}
+             for n, ms in ((1, 12.0), (2, 8.0), (4, 6.0), (8, 5.0))]
+    nested, raw = tmp_path / "scale.json", tmp_path / "lines.txt"
+    nested.write_text(json.dumps({"runs": [{"n": l["n_gpus"], "parsed": l, "stdout": "noise"} for l in lines]}))
+    raw.write_text("\n".join(json.dumps(l) for l in lines))
+    for f in (nested, raw):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "scaling_table.py"), str(f)], capture_output=True, text=True, check=True).stdout
+        rows = [json.loads(l) for l in out.splitlines()]
+        assert [r["n_gpus"] for r in rows] == [1, 2, 4, 8]
+        assert [r["speedup"] for r in rows] == [1.0, 1.5, 2.0, 2.4] and [r["efficiency"] for r in rows] == [1.0, 0.75, 0.5, 0.3]
+        assert rows[3]["ms_over_floor"] == 1.25 and rows[0]["speedup_limit_by_floor"] == 3.0
