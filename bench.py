@@ -56,7 +56,7 @@ import numpy as np  # noqa: E402
 VALU_FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz = one wave64 FMA per 2 cycles per SIMD
 VALU_FP64_PEAK_TFLOPS = 78.6      # v_fma_f64: half that rate (one wave64 instruction per 4 cycles)
 HBM_PEAK_GBS = 8000.0
-# What the part gives a stream of plain (un-packed) independent FMAs, measured with bin/valu_peak (profiles/r01_valu_peak.json): v_fma_f32 80.85 TFLOP/s
+# What the part gives a stream of plain (un-packed) independent FMAs, measured with bin/valu_peak (profiles/archive/r01_valu_peak.json): v_fma_f32 80.85 TFLOP/s
 # at 4 waves per SIMD, 84.65 at 8 (v_pk_fma_f32: 125-128); v_fma_f64 61.57 at 4 waves.  The render kernels run 5 (fp32) / 4 (fp64) waves per SIMD.
 PRACTICAL_FMA_TFLOPS = {32: 82.0, 64: 61.57}
 # Share of the fp64 main kernel's vector instructions that issue at the double-precision rate (v_*_f64: one wave64 instruction per 4 cycles; the rest --
@@ -83,7 +83,7 @@ def parse():
     ap.add_argument("--threads", type=int, default=0, help="reference --threads (block T x T); 0 = library tiling")
     ap.add_argument("--scene_source", default="grid", choices=("grid", "lds", "scalar", "lds_exact"))
     ap.add_argument("--schedule", default="sorted", choices=("sorted", "persistent", "static"))
-    ap.add_argument("--strip_rows", type=int, default=0, help="rows per interleaved strip; 0 = 8 for N <= 2, 2 for N >= 4 (profiles/r01_strip_rows_sweep.txt)")
+    ap.add_argument("--strip_rows", type=int, default=0, help="rows per interleaved strip; 0 = 8 for N <= 2, 2 for N >= 4 (profiles/archive/r01_strip_rows_sweep.txt)")
     ap.add_argument("--devices", default="", help="without a launcher: the device of every rank, e.g. 0,1,2,3 (default 0..N-1); a device may repeat")
     ap.add_argument("--gather", default="auto", choices=("auto", "rccl", "peer", "host"), help="transport of the in-library group (without a launcher, N > 1); auto falls back rccl -> peer -> host at gather time")
     ap.add_argument("--pmc", default="auto", choices=("auto", "live", "committed", "off"),
@@ -309,7 +309,7 @@ def roofline_object(args, st, segments_main_rank0, main_ms, pmc, pmc_note, world
                            "(static ISA share, tests/test_kernel_resources.py): %.2f cycles per instruction" % (100 * FP64_KERNEL_DP_SHARE, 2 + 2 * FP64_KERNEL_DP_SHARE)) +
                            "; achieved = frac x peak (the FMA slots of this precision: 64 lanes x 2 flop per 2 (fp32) / 4 (fp64) cycles per SIMD). null: no counters for THIS build",
             "practical_peak": {"value": PRACTICAL_FMA_TFLOPS[prec], "unit": "TFLOP/s",
-                               "what": "measured ceiling of a stream of plain independent %s at %d waves per SIMD (bin/valu_peak, profiles/r01_valu_peak.json): what the "
+                               "what": "measured ceiling of a stream of plain independent %s at %d waves per SIMD (bin/valu_peak, profiles/archive/r01_valu_peak.json): what the "
                                        "part gives un-packed vector code; v_pk_fma_f32 reaches 125-128" % (("v_fma_f32", 5) if prec == 32 else ("v_fma_f64", 4)),
                                "frac_of_practical": round(achieved / PRACTICAL_FMA_TFLOPS[prec], 4) if achieved is not None else None},
             "counters_from": pmc_note, "build_id": pmc.get("build_id") if pmc else None, "issued": issued,

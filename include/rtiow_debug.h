@@ -21,6 +21,9 @@ int rtiow_debug_read_costs(rtiow_handle h, uint32_t* own, uint32_t* smoothed, si
  * {t_start, t_pool_exhausted, t_end (100 MHz ticks), iterations alone, iterations cooperative,
  * pixels taken, 0, 0}. */
 int rtiow_debug_timeline(rtiow_handle h, int threads_per_block_row, uint64_t* out_words, size_t cap_words, int* waves);
+/* One (untimed, counting) persistent render: per local pixel 4 words {when a lane took it, when it finished (100 MHz ticks, low 32 bits),
+ * segments it ran in the launch, wave that ran it} of the LAST launch that rendered it (the main launch of the sorted schedule). */
+int rtiow_debug_pixel_times(rtiow_handle h, int threads_per_block_row, uint32_t* out_words, size_t cap_words);
 int rtiow_debug_ops(rtiow_handle h, int op, size_t n, const void* a, const void* b, const void* c, void* out);
 /* hit_world (hittable.h:80-98) alone, with the handle's scene and scene source, on n caller-supplied rays
  * {ox,oy,oz,dx,dy,dz} in the handle's precision: nearest root (+inf: none) and sphere index (-1: none) per ray.

@@ -96,7 +96,7 @@ HIP_SYMBOLS = [
 ]
 # include/rtiow_debug.h: exported by lib/librtiow_hip_debug.so (the test build) only
 DEBUG_SYMBOLS = [
-    "rtiow_debug_read_rng", "rtiow_debug_read_costs", "rtiow_debug_timeline", "rtiow_debug_ops", "rtiow_debug_jump_matrices", "rtiow_debug_grid_plan", "rtiow_debug_hit_world",
+    "rtiow_debug_read_rng", "rtiow_debug_read_costs", "rtiow_debug_timeline", "rtiow_debug_pixel_times", "rtiow_debug_ops", "rtiow_debug_jump_matrices", "rtiow_debug_grid_plan", "rtiow_debug_hit_world",
     "rtiow_debug_gather_schedule",
 ]
 HOST_SYMBOLS = [
@@ -529,6 +529,13 @@ class Renderer:
         n = ctypes.c_int(0)
         self._check(self._lib.rtiow_debug_timeline(self._h, int(threads), out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), out.size, ctypes.byref(n)))
         return out[: n.value]
+
+    def debug_pixel_times(self, threads=0):
+        """uint32 [rows, W, 4]: per pixel {taken, finished (100 MHz ticks), segments, wave} in the last launch that rendered it."""
+        self._need_debug()
+        out = np.zeros((self.local_rows, self.width, 4), np.uint32)
+        self._check(self._lib.rtiow_debug_pixel_times(self._h, int(threads), out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), ctypes.c_size_t(out.size)))
+        return out
 
     def debug_ops(self, op, a, b=None, c=None):
         self._need_debug()

@@ -24,7 +24,7 @@ __device__ __forceinline__ int cost_bin(unsigned c) { return c < (unsigned)COST_
 // neighbours in the image: a rank's strip in a sharded frame (windows that cross into the rank's next strip, N x
 // strip rows away, rank the pixels worse: 1/4 frame 6.4 -> 7.2 ms), the whole frame on one rank (until the end of
 // round 2 the window stopped at the default 8-row strips there too: 1280x720 8.3 -> 7.9 ms, headline 13.4 -> 13.3,
-// profiles/r02_handout_study/sweep8_smoothing_window.txt; half-widths 5-10 are equal, sweep9).
+// profiles/archive/r02_handout_study/sweep8_smoothing_window.txt; half-widths 5-10 are equal, sweep9).
 // One workgroup smooths a 64 x 16 tile from LDS: the tile with its halo, then the horizontal window sums of every
 // row it needs, then the vertical sums (26 LDS reads per pixel instead of 169 cached global loads: 61 -> 20 us on
 // the full frame).  Integer sums: the same values in any order.

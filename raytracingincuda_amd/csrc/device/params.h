@@ -67,6 +67,7 @@ template <class T> struct ColdParams {
     // wave 0 of the first solo_waves workgroups, which take nothing else until those pixels are done.
     int solo_waves, solo_lanes;
     unsigned long long* timeline;     // COUNT variant, optional: per wave {t_start, t_exhausted, t_end, iters_normal, iters_coop, pixels, 0, 0}
+    uint32_t* pixel_times;            // COUNT variant, optional (rtiow_debug_pixel_times): per local pixel {taken, finished (100 MHz ticks, low 32 bits), segments in this launch, wave}
 };
 
 // The camera (camera.h:10-30 as camera::initialize leaves it): 19 scalars that only gen_primary reads, once per

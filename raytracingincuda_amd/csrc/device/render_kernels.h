@@ -69,7 +69,7 @@ constexpr int POOL = 64;
 // Bounded rejection loop of random_unit_vector (shade_step<T, true>, fp64 persistent kernels): rounds a wave runs per
 // iteration before the lanes still without a candidate resume in the next one.  Unbounded in the drain, where a lone
 // chain's latency counts and no other lane waits for the rounds.  Measured on one box against the blocking loop
-// (profiles/r03_ab_carry_over_unit_vector_rounds.jsonl, r03_ab_retry_unit_vector_rounds.jsonl): the main launch issues
+// (profiles/r03/r03_ab_carry_over_unit_vector_rounds.jsonl, r03_ab_retry_unit_vector_rounds.jsonl): the main launch issues
 // 5-6 % fewer vector instructions in both precisions and fp64 -- whose round is six XORWOW steps -- renders 5 % faster;
 // fp32 does not: a lane that waits costs its wave a whole iteration's worth of the work every iteration does whatever
 // the lane count (hit_world's set-up and direct list, the shade prologue: half of an iteration), which is what the
@@ -177,6 +177,7 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
     }
     unsigned long long t_start = 0, t_exh = 0;
     unsigned int it_normal = 0, it_coop = 0, n_pixels = 0;
+    unsigned int px_id = 0, px_taken = 0;        // COUNT: the lane's pixel and when it took it (ColdParams::pixel_times)
     if (COUNT) t_start = __builtin_amdgcn_s_memrealtime();
     const int lanes_left = (int)blockDim.x - (int)(threadIdx.x & ~63u);
     const int wave_lanes = lanes_left < 64 ? lanes_left : 64;   // partial last wave of a T x T block
@@ -230,6 +231,7 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
                         }
                         st.sample = c.s_begin; st.depth = 0;
                         cost = 0;
+                        if (COUNT) { px_id = (unsigned)lp; px_taken = (unsigned)__builtin_amdgcn_s_memrealtime(); }
                         if (c.stage_by_slot) lp = (size_t)slot;      // where this pixel will be stored (ColdParams::stage_by_slot); the state is loaded
                         if (COUNT) ++n_pixels;
                         if (c.s_begin < S) { alive = true; fresh = true; }
@@ -479,6 +481,11 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
                 PATH_STAT(PS_FINISH_PIXEL);
                 const auto& c = cold_of(p);
                 if (COUNT) atomicMax(c.seg_counter + 2, (unsigned long long)cost);   // a pixel's samples are ONE sequential chain: the frame cannot be shorter than the longest
+                if (COUNT && c.pixel_times) {
+                    uint32_t* o = c.pixel_times + 4 * (size_t)px_id;
+                    o[0] = px_taken; o[1] = (unsigned)__builtin_amdgcn_s_memrealtime(); o[2] = cost;
+                    o[3] = blockIdx.x * ((blockDim.x + 63) >> 6) + (threadIdx.x >> 6);
+                }
                 finish_pixel<T>(c, lp, st, cost); alive = false;
             }
         }

@@ -13,7 +13,7 @@ __device__ __forceinline__ uint32_t rng_next(Rng& s) {
     uint32_t t = s.v0 ^ (s.v0 >> 2);
     s.v0 = s.v1; s.v1 = s.v2; s.v2 = s.v3; s.v3 = s.v4;
     // gfx950's three-input bit operation (truth table 0x96 = a^b^c) takes one of the four xors: 6 instead
-    // of 7 vector instructions per draw (profiles/r02_ab_xorwow_bitop3.jsonl: -2.4 % SQ_INSTS_VALU, -1.2 % time)
+    // of 7 vector instructions per draw (profiles/archive/r02_ab_xorwow_bitop3.jsonl: -2.4 % SQ_INSTS_VALU, -1.2 % time)
     // t << 1 as t + t: on gfx950 v_lshlrev_b32 issues at 5.3 cycles per wave-instruction, v_add_u32 at 3.7
     // (bin/valu_cost); the compiler turns a source-level t + t back into the shift, hence the one-line asm.
     uint32_t t2;

@@ -59,6 +59,7 @@ struct rtiow_handle_s {
     size_t timeline_cap_waves = 0;            // waves the debug timeline buffer holds
     unsigned int* work_counter = nullptr;
     unsigned long long* timeline = nullptr;   // debug: set only during rtiow_debug_timeline
+    uint32_t* pixel_times = nullptr;          // debug: set only during rtiow_debug_pixel_times
     int probe_n = 0; const void* probe_rays = nullptr; void* probe_t = nullptr; int* probe_idx = nullptr;   // debug: set only during rtiow_debug_hit_world
     rtiow_stats stats{};
 };

@@ -77,6 +77,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     p.screen_offset = (int)lds;
     if (p.use_screen) lds += sizeof(float) * 4 * (size_t)h->n_padded;
     p.cold.timeline = nullptr;                                    // set below, once the grid is known
+    p.cold.pixel_times = seg_counter ? h->pixel_times : nullptr;
     // shade records ride along in LDS while a workgroup's share stays within 1/5 of the CU's LDS
     const size_t coop_bytes = coop_scratch;
     const size_t shade_bytes = (sizeof(T) * 12 * (size_t)h->n + 15) / 16 * 16;
@@ -135,12 +136,12 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
         // `lane_cap` lanes of every wave take pixels.  More waves are busy, each permanently in the
         // cooperative mode, where its idle lanes split the sphere loops of the live ones: a trip gets
         // shorter, and with so little work the frame is as long as its longest chain of trips.
-        // Measured (profiles/r01_lane_cap_sweep.txt): scene 1 320x192x10 2.27 -> 1.06 ms, 640x384x100
+        // Measured (profiles/archive/r01_lane_cap_sweep.txt): scene 1 320x192x10 2.27 -> 1.06 ms, 640x384x100
         // 19.4 -> 17.0 ms; frames with at least one pool per wave are unchanged (cap 64).
         int lane_cap = 64;
         {
             const long long pools = tile_slots / POOL, waves = (long long)h->num_cus * per_cu * waves_per_block;
-            while (lane_cap > 16 && pools * (64 / lane_cap) < waves) lane_cap >>= 1;  // the largest share that keeps every wave busy; not below 16 (with the grid walk 8-lane waves lose: scene 1 320x192x100 6.85 vs 5.96 ms, profiles/r02_lane_cap_sweep.jsonl)
+            while (lane_cap > 16 && pools * (64 / lane_cap) < waves) lane_cap >>= 1;  // the largest share that keeps every wave busy; not below 16 (with the grid walk 8-lane waves lose: scene 1 320x192x100 6.85 vs 5.96 ms, profiles/archive/r02_lane_cap_sweep.jsonl)
             lane_cap = tuned("RTIOW_TUNE_LANE_CAP", lane_cap);
         }
         p.lane_cap = lane_cap;
@@ -171,7 +172,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             // ~3 us per trip among 63 other pixels.  Two heavy pixels alone in a wave share every sphere loop with the
             // idle lanes and skip the divergent work of wave-mates.  Which pixels: the top of the cost ranking.  How
             // many waves: more than ~5 % of the resident waves cost more throughput than the chains gain; measured per
-            // fill level (profiles/r02_handout_study/): 1/8 frame 6.96 -> 5.65 ms with 128 waves (5.78 with 256),
+            // fill level (profiles/archive/r02_handout_study/): 1/8 frame 6.96 -> 5.65 ms with 128 waves (5.78 with 256),
             // 1/4 frame 7.85 -> 6.61 with 256 (7.03 with 128), 1/2 frame 8.43 -> 8.21, 1280x720 8.82 -> 8.34; the full
             // frame (6.3 pools per wave) loses 1-2 % and keeps the plain kernel.  Outlier chains need a bounce limit
             // that lets rare long paths exist: at 10 bounces the solo waves cost 4-11 % on both scenes, at 25 scene 3
@@ -226,7 +227,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             HIP_TRY(h, hipMemsetAsync(h->order, 0xff, ((size_t)total_pools * POOL + (size_t)solo_slots) * sizeof(int), h->stream));
             const int sort_blocks = (npix + 255) / 256;
             const uint32_t* rank_by = h->cost;
-            int smooth_hw = 6;                          // 13 x 13 window: profiles/r02_cost_smoothing_sweep.jsonl
+            int smooth_hw = 6;                          // 13 x 13 window: profiles/archive/r02_cost_smoothing_sweep.jsonl
             smooth_hw = tuned("RTIOW_TUNE_SMOOTH", smooth_hw);
             if (smooth_hw > 0) {
                 if (smooth_hw > 24) smooth_hw = 24;      // 2 x (tile + halo) words of LDS: 37 KB at 24
@@ -249,14 +250,14 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             // in one pool, the groups go round-robin over the block's pools.  Coherent groups mean fewer
             // distinct spheres pass the screen per wave (8.9 exact blocks per wave-iteration with single
             // ranks vs 3.6 in tile order); mixed costs in a pool let a heavy pixel finish in the fast
-            // cooperative mode, which is what small shards need.  Measured (profiles/r01_deal_group_sweep.txt):
+            // cooperative mode, which is what small shards need.  Measured (profiles/archive/r01_deal_group_sweep.txt):
             // full frame 24.1 -> 22.5 ms with 16-32, half frame 14.7 -> 14.0 with 8, quarter and eighth
             // frames are fastest with 1.
             const double pools_per_wave = (double)total_pools / (double)resident_waves;
             // With the grid walk (a lane's cost follows ITS ray) coherence pays more: whole pools of 64 neighbouring
-            // ranks, 15.3 -> 14.7 ms on the full frame (profiles/r02_tune_sweep.jsonl) and, once the ranks come from
+            // ranks, 15.3 -> 14.7 ms on the full frame (profiles/archive/r02_tune_sweep.jsonl) and, once the ranks come from
             // the smoothed cost, on every frame with at least 2.5 pools per wave (1280x720: 9.3 ms with groups of 1,
-            // 11.4 with 8, 8.7 with 64; profiles/r02_cost_smoothing_sweep.jsonl); smaller shards keep single ranks.
+            // 11.4 with 8, 8.7 with 64; profiles/archive/r02_cost_smoothing_sweep.jsonl); smaller shards keep single ranks.
             int deal_group = pools_per_wave >= 2.5 ? 64 : 1;
             deal_group = tuned("RTIOW_TUNE_DEAL", deal_group);
             const int scatter_blocks = ((p.cold.W + 63) / 64) * ((h->local_rows + 63) / 64);   // one per 64 x 64 super-tile

@@ -528,6 +528,25 @@ int rtiow_debug_timeline(rtiow_handle h, int threads_per_block_row, uint64_t* ou
     return 0;
 }
 
+int rtiow_debug_pixel_times(rtiow_handle h, int threads_per_block_row, uint32_t* out_words, size_t cap_words) {
+    if (!h || !out_words) return RTIOW_E_BADARG;
+    if (h->schedule == RTIOW_SCHED_STATIC) return fail_arg(h, RTIOW_E_STATE, "rtiow_debug_pixel_times needs a persistent schedule");
+    if (!h->have_camera) return fail_arg(h, RTIOW_E_STATE, "rtiow_debug_pixel_times before rtiow_set_camera");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t words = (size_t)h->local_rows * img_w(h) * 4;
+    if (cap_words < words) return fail_arg(h, RTIOW_E_BADARG, "rtiow_debug_pixel_times: buffer too small");
+    DeviceScratch buf;
+    HIP_TRY(h, buf.alloc(words * sizeof(uint32_t)));
+    HIP_TRY(h, hipMemset(buf.ptr, 0, words * sizeof(uint32_t)));
+    h->pixel_times = (uint32_t*)buf.ptr;
+    uint64_t seg = 0;
+    const int rc = rtiow_count_segments(h, threads_per_block_row, &seg);
+    h->pixel_times = nullptr;
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpy(out_words, buf.ptr, words * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int rtiow_debug_hit_world(rtiow_handle h, int n, const void* rays, void* t_out, int32_t* index_out) {
     if (!h || n <= 0 || !rays || !t_out || !index_out) return RTIOW_E_BADARG;
     if (!h->have_camera || h->n == 0) return fail_arg(h, RTIOW_E_STATE, "rtiow_debug_hit_world before rtiow_set_scene/rtiow_set_camera");

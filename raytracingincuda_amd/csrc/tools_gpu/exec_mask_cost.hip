@@ -1,7 +1,7 @@
 // exec_mask_cost.hip -- does a wave64 vector instruction cost less issue time when only some lanes are enabled?
 //
 // The render path is bound by vector issue and its divergent blocks (rejection rounds, grid steps, IEEE tails) run
-// with ~11 of 64 lanes enabled (profiles/r02_path_stats.json; SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU says a third
+// with ~11 of 64 lanes enabled (profiles/archive/r02_path_stats.json; SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU says a third
 // of the lanes on average).  A SIMD-32 executes a wave64 instruction in two passes of 32 lanes; if the hardware
 // skipped a pass whose 32 lanes are all disabled, packing the live lanes of a divergent block into one half of the
 // wave would halve its cost.  This probe times 16 independent v_fma_f32 / v_xor_b32 / v_pk_fma_f32 chains per lane

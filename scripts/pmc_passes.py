@@ -15,7 +15,7 @@ The record carries `build_id` = rtiow_build_id() of the library that rendered (S
 bench.py uses a committed record only when that id equals the id of the library it has loaded, and prints null
 otherwise -- a counter figure can never outlive the kernel it was measured on.
 
-    python3 scripts/pmc_passes.py --out profiles/r03_pmc_records.json [--scene_id 3 --width 1920 ...] [--passes sq,fetch,write]
+    python3 scripts/pmc_passes.py --out profiles/r03/r03_pmc_records.json [--scene_id 3 --width 1920 ...] [--passes sq,fetch,write]
 
 bench.py imports collect() for its live leg (a child process per pass, started before bench.py touches the GPU).
 """
@@ -129,7 +129,7 @@ def derive(main, launch_ms=None):
         if main.get("SQ_THREAD_CYCLES_VALU") and main.get("SQ_ACTIVE_INST_VALU"):
             # lanes enabled per vector instruction / 64.  Calibrated on a kernel that runs every instruction with all 64
             # lanes (bin/valu_peak under the same counters: SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = 64.00,
-            # profiles/r03_lane_counter_calibration.json)
+            # profiles/r03/r03_lane_counter_calibration.json)
             d["active_lane_frac"] = main["SQ_THREAD_CYCLES_VALU"] / (main["SQ_ACTIVE_INST_VALU"] * 64.0)
         if main.get("GRBM_GUI_ACTIVE"):
             cycles = main["GRBM_GUI_ACTIVE"] / 8.0                 # rocprofv3 sums the 8 XCDs

@@ -1,7 +1,7 @@
 """The AMD analogue of the reference's global / const / tex comparison (README.md:7-12): the same
 frame with every scene source -- uniform grid over the LDS tables (default), screened loop over the LDS tables,
 exact loop over the LDS tables, wave-uniform scalar loads through the scalar cache -- side by side, fp32 and fp64.
-Every source gives the same image (the md5 column).     python scripts/scene_source_compare.py > profiles/r02_scene_source_comparison.md"""
+Every source gives the same image (the md5 column).     python scripts/scene_source_compare.py > profiles/archive/r02_scene_source_comparison.md"""
 import hashlib, sys
 import numpy as np
 sys.path.insert(0, '.')

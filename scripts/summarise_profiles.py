@@ -2,12 +2,14 @@
 bench lines, the rocprofv3 kernel-stats table, the per-launch agreement check between rocprofv3 and bench.py's HIP
 events, and the counter records (profiles/pmc_records.json: what `bench.py --pmc committed` reads -- each record
 carries the build id of the library it was measured on).
-Usage: summarise_profiles.py [round_tag]   (default r03)"""
+Usage: summarise_profiles.py [round_tag]   (default r04; files land in profiles/<round_tag>/)"""
 import csv, glob, json, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "final")
-dst = os.path.join(root, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+top = os.path.join(root, "profiles")
+dst = os.path.join(top, tag)                      # one directory per round; profiles/pmc_records.json (what bench.py --pmc committed reads) stays at the top
+os.makedirs(dst, exist_ok=True)
 
 def last_json(path):
     return json.loads(open(path).read().strip().splitlines()[-1])
@@ -15,11 +17,11 @@ def last_json(path):
 for f in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
     name = os.path.basename(f)[:-5]
     try:
-        json.dump(last_json(f), open(os.path.join(dst, "%s_%s.json" % (tag, name)), "w"), indent=1)
+        json.dump(last_json(f), open(os.path.join(dst, "%s.json" % name), "w"), indent=1)
     except (ValueError, IndexError):
         print("skipped (no JSON line):", name)
 stats = glob.glob(os.path.join(src, "ktrace", "**", "*kernel_stats.csv"), recursive=True)[0]
-shutil.copy(stats, os.path.join(dst, "%s_kernel_stats.csv" % tag))
+shutil.copy(stats, os.path.join(dst, "kernel_stats.csv"))
 b = last_json(os.path.join(src, "bench_under_rocprof.json"))
 rows = list(csv.DictReader(open(stats)))
 def row(part):
@@ -34,13 +36,13 @@ agree = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --step
          "rocprof_all_kernels_per_step_ms": (float(main["AverageNs"]) + (float(pre["AverageNs"]) if pre else 0.0) + (float(place["AverageNs"]) if place else 0.0)
                                              + sum(float(r["AverageNs"]) for r in rows if "cost_" in r["Name"])) / 1e6,
          "bench_step_kernel_ms_mean": b["step"]["kernel_ms_mean"]}
-json.dump(agree, open(os.path.join(dst, "%s_rocprof_vs_bench.json" % tag), "w"), indent=1)
+json.dump(agree, open(os.path.join(dst, "rocprof_vs_bench.json"), "w"), indent=1)
 print(json.dumps(agree, indent=1))
 if os.path.exists(os.path.join(src, "pmc_records.json")):
     rec = json.load(open(os.path.join(src, "pmc_records.json")))
-    json.dump(rec, open(os.path.join(dst, "pmc_records.json"), "w"), indent=1, sort_keys=True)
+    json.dump(rec, open(os.path.join(top, "pmc_records.json"), "w"), indent=1, sort_keys=True)
     for k, r in rec.items():
         print(k, r.get("build_id", "")[:12], json.dumps(r.get("derived_main")))
 for name, out in (("path_stats.json", "path_stats.json"), ("path_stats_scene1.json", "path_stats_scene1.json"), ("scaling_estimate.jsonl", "scaling_estimate_single_gpu.jsonl"), ("accounting.jsonl", "accounting_by_age_class.jsonl")):
     if os.path.exists(os.path.join(src, name)):
-        shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, out)))
+        shutil.copy(os.path.join(src, name), os.path.join(dst, out))

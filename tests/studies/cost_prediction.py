@@ -6,7 +6,7 @@ For each scene at 640x360: segments of samples [0,3) ("prepass") and of samples 
 predictors: the pixel's own prepass cost and box means of it; reported: correlation with the rest, and where in
 the heavy-first order the truly heaviest 0.5 % of the pixels would start (fraction of the pixels handed out before).
 
-    python tests/studies/cost_prediction.py > profiles/r02_cost_prediction_study.txt
+    python tests/studies/cost_prediction.py > profiles/archive/r02_cost_prediction_study.txt
 """
 import os
 import sys
