@@ -177,7 +177,6 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
     }
     unsigned long long t_start = 0, t_exh = 0;
     unsigned int it_normal = 0, it_coop = 0, n_pixels = 0;
-    unsigned int px_id = 0, px_taken = 0;        // COUNT: the lane's pixel and when it took it (ColdParams::pixel_times)
     if (COUNT) t_start = __builtin_amdgcn_s_memrealtime();
     const int lanes_left = (int)blockDim.x - (int)(threadIdx.x & ~63u);
     const int wave_lanes = lanes_left < 64 ? lanes_left : 64;   // partial last wave of a T x T block
@@ -231,7 +230,9 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
                         }
                         st.sample = c.s_begin; st.depth = 0;
                         cost = 0;
-                        if (COUNT) { px_id = (unsigned)lp; px_taken = (unsigned)__builtin_amdgcn_s_memrealtime(); }
+#ifdef RTIOW_PIXEL_TIMES      // study builds only (scripts/pixel_finish_study.py): the fp64 counting kernel has no registers to spare
+                        if (COUNT && c.pixel_times) c.pixel_times[4 * lp] = (unsigned)__builtin_amdgcn_s_memrealtime();   // taken (no register carried to the finish)
+#endif
                         if (c.stage_by_slot) lp = (size_t)slot;      // where this pixel will be stored (ColdParams::stage_by_slot); the state is loaded
                         if (COUNT) ++n_pixels;
                         if (c.s_begin < S) { alive = true; fresh = true; }
@@ -481,11 +482,15 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
                 PATH_STAT(PS_FINISH_PIXEL);
                 const auto& c = cold_of(p);
                 if (COUNT) atomicMax(c.seg_counter + 2, (unsigned long long)cost);   // a pixel's samples are ONE sequential chain: the frame cannot be shorter than the longest
+#ifdef RTIOW_PIXEL_TIMES
                 if (COUNT && c.pixel_times) {
-                    uint32_t* o = c.pixel_times + 4 * (size_t)px_id;
-                    o[0] = px_taken; o[1] = (unsigned)__builtin_amdgcn_s_memrealtime(); o[2] = cost;
+                    size_t px = lp;                                  // the local pixel: lp itself, or -- staged stores -- what the order holds for the slot
+                    if (c.stage_by_slot) { const int e = c.order[lp]; px = (size_t)(e >> 16) * c.W + (size_t)(e & 0xffff); }
+                    uint32_t* o = c.pixel_times + 4 * px;
+                    o[1] = (unsigned)__builtin_amdgcn_s_memrealtime(); o[2] = cost;
                     o[3] = blockIdx.x * ((blockDim.x + 63) >> 6) + (threadIdx.x >> 6);
                 }
+#endif
                 finish_pixel<T>(c, lp, st, cost); alive = false;
             }
         }

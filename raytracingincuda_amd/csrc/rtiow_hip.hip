@@ -530,6 +530,9 @@ int rtiow_debug_timeline(rtiow_handle h, int threads_per_block_row, uint64_t* ou
 
 int rtiow_debug_pixel_times(rtiow_handle h, int threads_per_block_row, uint32_t* out_words, size_t cap_words) {
     if (!h || !out_words) return RTIOW_E_BADARG;
+#ifndef RTIOW_PIXEL_TIMES
+    return fail_arg(h, RTIOW_E_STATE, "rtiow_debug_pixel_times: this build was compiled without -DRTIOW_PIXEL_TIMES (scripts/pixel_finish_study.py builds lib/ab/pixel_times.so)");
+#endif
     if (h->schedule == RTIOW_SCHED_STATIC) return fail_arg(h, RTIOW_E_STATE, "rtiow_debug_pixel_times needs a persistent schedule");
     if (!h->have_camera) return fail_arg(h, RTIOW_E_STATE, "rtiow_debug_pixel_times before rtiow_set_camera");
     HIP_TRY(h, hipSetDevice(h->device));

@@ -4,6 +4,12 @@ import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracingincuda_amd as rt
+from raytracingincuda_amd import build
+# the per-pixel stamps are compiled into a study build only (-DRTIOW_PIXEL_TIMES; the fp64 counting kernel has no registers to spare for them)
+lib = os.path.join(build.LIB, "ab", "pixel_times.so")
+if not os.path.exists(lib):
+    build.build_variant("pixel_times", ["-DRTIOW_DEBUG_API", "-DRTIOW_PIXEL_TIMES"], verbose=False)
+os.environ["RTIOW_HIP_DEBUG_LIBRARY"] = lib
 a = sys.argv[1:]
 scene, W, H, S, B = (int(x) for x in a[:5]) if len(a) >= 5 else (3, 1920, 1080, 100, 50)
 r = rt.Renderer(0, 32, debug=True); r.set_camera(rt.camera(32, W, H, S, B)); r.set_scene(rt.build_scene(scene, 32))
