@@ -36,6 +36,7 @@ struct rtiow_handle_s {
     uint32_t* rng = nullptr;
     size_t rng_pixels = 0;
     bool rng_ready = false;
+    uint32_t* rng_low_table = nullptr;            // J^lo * s0 for lo < 2^XW_LOW_BITS (xw_low_table_kernel), per rtiow_init_rng
     uint32_t* jump = nullptr;
     int jump_count = 0;                           // matrices of `jump` that are filled: enough for the bits of the largest pixel index so far
     // framebuffer

@@ -168,7 +168,7 @@ int rtiow_destroy(rtiow_handle h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     void* bufs[] = {h->geom_a, h->shade_tbl, h->geom_s, h->grid_blob, h->cost_rank, h->rng, h->jump, h->work_counter, h->mid, h->slot_of, h->staged,
-                    h->cost, h->order, h->sort_scratch, h->levels, h->fb_external ? nullptr : h->fb};
+                    h->cost, h->order, h->sort_scratch, h->levels, h->rng_low_table, h->fb_external ? nullptr : h->fb};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -244,6 +244,7 @@ int rtiow_init_rng(rtiow_handle h, uint64_t seed) {
     const int W = img_w(h), H = img_h(h);
     int index_bits = 1;                                      // bits of the largest GLOBAL pixel index W*H-1
     while (index_bits < XW_JUMPS && ((uint64_t)W * (uint64_t)H - 1) >> index_bits) ++index_bits;
+    if (index_bits < XW_LOW_BITS) index_bits = XW_LOW_BITS;   // xw_low_table_kernel applies the first XW_LOW_BITS matrices whatever the frame size
     if (h->jump_count < index_bits) {                        // 31 squarings for all 32 matrices take 2.4 ms on the host; a 1080p frame needs 21
         std::vector<uint32_t> m = build_sequence_jump_matrices(false, index_bits);
         if (!h->jump) HIP_TRY(h, hipMalloc((void**)&h->jump, (size_t)XW_JUMPS * XW_MAT_WORDS * sizeof(uint32_t)));
@@ -265,7 +266,11 @@ int rtiow_init_rng(rtiow_handle h, uint64_t seed) {
         HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
         const int threads = 256;
         const unsigned blocks = (unsigned)((npix + threads - 1) / threads);
-        hipLaunchKernelGGL(rng_init_kernel, dim3(blocks), dim3(threads), 0, h->stream, h->rng, h->jump, d0, s0, s1, s2, s3, s4,
+        // J^lo * s0 for the 2^XW_LOW_BITS low parts of a pixel index (once per seed), then every pixel from its entry (device/xorwow.h)
+        if (!h->rng_low_table) HIP_TRY(h, hipMalloc((void**)&h->rng_low_table, sizeof(uint32_t) * XW_WORDS * ((size_t)1 << XW_LOW_BITS)));
+        hipLaunchKernelGGL(xw_low_table_kernel, dim3((1u << XW_LOW_BITS) / 256), dim3(256), 0, h->stream, h->rng_low_table, h->jump, s0, s1, s2, s3, s4);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL(rng_init_kernel, dim3(blocks), dim3(threads), 0, h->stream, h->rng, h->jump, (const uint32_t*)h->rng_low_table, d0,
                            W, H, h->local_rows, h->rank, h->nranks, h->strip_rows);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
