@@ -12,20 +12,21 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 cd "$ROOT"
 python3 bench.py --steps 20 --warmup 3 > "$OUT/bench_n1.json"
 echo "bench fp32 done"
-python3 bench.py --steps 10 --warmup 2 --precision 64 --no-cpu-baseline > "$OUT/bench_n1_f64.json"
-python3 bench.py --steps 5 --warmup 2 --scene_id 1 --no-cpu-baseline > "$OUT/bench_n1_scene1.json"
-python3 bench.py --steps 10 --warmup 2 --schedule static --threads 8 --no-cpu-baseline > "$OUT/bench_n1_static_t8.json"
-python3 bench.py --steps 10 --warmup 2 --scene_source lds --no-cpu-baseline --pmc off > "$OUT/bench_n1_screen_only.json"
+python3 bench.py --steps 10 --warmup 2 --precision 64 --no-cpu-baseline --no-extra-configs > "$OUT/bench_n1_f64.json"
+python3 bench.py --steps 5 --warmup 2 --scene_id 1 --no-cpu-baseline --no-extra-configs > "$OUT/bench_n1_scene1.json"
+python3 bench.py --steps 10 --warmup 2 --schedule static --threads 8 --no-cpu-baseline --no-extra-configs > "$OUT/bench_n1_static_t8.json"
+python3 bench.py --steps 10 --warmup 2 --scene_source lds --no-cpu-baseline --no-extra-configs --pmc off > "$OUT/bench_n1_screen_only.json"
 # the other BASELINE.json configs: [1] scene 1 320x192 10 spp 25 bounces, [2] 1280x720, [4] fp64 at 500 spp
-python3 bench.py --steps 20 --warmup 3 --scene_id 1 --width 320 --height 192 --samples 10 --bounces 25 --threads 8 --no-cpu-baseline > "$OUT/bench_config2_scene1_320x192.json"
-python3 bench.py --steps 20 --warmup 3 --width 1280 --height 720 --threads 8 --no-cpu-baseline > "$OUT/bench_config3_1280x720.json"
-python3 bench.py --steps 5 --warmup 1 --precision 64 --samples 500 --no-cpu-baseline > "$OUT/bench_config5_f64_500spp.json"
+python3 bench.py --steps 20 --warmup 3 --scene_id 1 --width 320 --height 192 --samples 10 --bounces 25 --threads 8 --no-cpu-baseline --no-extra-configs > "$OUT/bench_config2_scene1_320x192.json"
+python3 bench.py --steps 20 --warmup 3 --width 1280 --height 720 --threads 8 --no-cpu-baseline --no-extra-configs > "$OUT/bench_config3_1280x720.json"
+python3 bench.py --steps 5 --warmup 1 --precision 64 --samples 500 --no-cpu-baseline --no-extra-configs > "$OUT/bench_config5_f64_500spp.json"
+python3 bench.py --steps 5 --warmup 1 --width 3840 --height 2160 --no-cpu-baseline --no-extra-configs > "$OUT/bench_3840x2160.json"
 # N = 2 without a launcher (the in-library group; both ranks on the one device) and under torch.distributed.run at world size 1
 python3 bench.py --gpus 2 --devices 0,0 --steps 10 --warmup 2 > "$OUT/bench_group_n2_one_device.json"
-python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_n1_rccl_world_size_1.json"
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline --no-extra-configs > "$OUT/bench_n1_rccl_world_size_1.json"
 echo "bench variants done"
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/ktrace" -o kt --output-format csv -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-scaling-probe --pmc off > "$OUT/bench_under_rocprof.json" 2> "$OUT/ktrace.log"
+rocprofv3 --kernel-trace --stats -d "$OUT/ktrace" -o kt --output-format csv -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-extra-configs --no-scaling-probe --pmc off > "$OUT/bench_under_rocprof.json" 2> "$OUT/ktrace.log"
 echo "kernel trace done"
 cd "$ROOT"
 for cfg in "" "--precision 64" "--scene_id 1" "--precision 64 --samples 500" "--width 1280 --height 720" "--scene_id 1 --width 320 --height 192 --samples 10 --bounces 25 --threads 8"; do
@@ -34,5 +35,12 @@ done
 echo "pmc records done"
 if [ -f raytracingincuda_amd/lib/librtiow_hip_stats.so ]; then python3 scripts/path_stats_probe.py > "$OUT/path_stats.json"; python3 scripts/path_stats_probe.py 1 > "$OUT/path_stats_scene1.json"; fi
 python3 scripts/scaling_probe.py > "$OUT/scaling_estimate.jsonl"
+# the drop-in executables: the reference's own benchmark grid and the BASELINE.json configurations (one cold process per run), text and binary files
+python3 scripts/harness_compare.py final > "$OUT/harness_compare.log" 2>&1 || true
+cp gpurun_out/harness/*.csv gpurun_out/harness/harness_vs_reference.md "$OUT/" 2>/dev/null || true
+BASELINE_CONFIGS=1 RUNS=3 STATS_JSONL="$OUT/harness_baseline_configs_stats.jsonl" bash tools/hip_benchmark.sh float "$OUT/harness_baseline_configs_float.csv" 2> /dev/null
+BASELINE_CONFIGS=1 RUNS=2 STATS_JSONL="$OUT/harness_baseline_configs_stats_double.jsonl" bash tools/hip_benchmark.sh double "$OUT/harness_baseline_configs_double.csv" 2> /dev/null
+mkdir -p /tmp/e2e_p6 && (cd /tmp/e2e_p6 && for i in 1 2 3; do "$ROOT/raytracingincuda_amd/bin/global-float-hip-raytrace" --scene_id 3 --width 1920 --height 1080 --samples 100 --bounces 50 --threads 8 --stats --ppm_format p6; done) > "$OUT/e2e_1080p_p6.log" 2>&1
+echo "harness done"
 python3 scripts/accounting_probe.py > "$OUT/accounting.jsonl"
 echo "all done"

@@ -46,3 +46,5 @@ if os.path.exists(os.path.join(src, "pmc_records.json")):
 for name, out in (("path_stats.json", "path_stats.json"), ("path_stats_scene1.json", "path_stats_scene1.json"), ("scaling_estimate.jsonl", "scaling_estimate_single_gpu.jsonl"), ("accounting.jsonl", "accounting_by_age_class.jsonl")):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, out))
+for f in sorted(glob.glob(os.path.join(src, "harness_*")) + glob.glob(os.path.join(src, "*timing_100sample.csv")) + glob.glob(os.path.join(src, "e2e_*.log"))):
+    shutil.copy(f, os.path.join(dst, os.path.basename(f)))
