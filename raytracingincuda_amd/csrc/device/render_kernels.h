@@ -66,14 +66,14 @@ render_kernel(const RenderParams<T> p) {
 // tile-major from the BOTTOM of the image up (ground and spheres first, cheap sky last) to
 // keep the drain tail short.  Per-pixel work and RNG streams are unchanged => same image.
 constexpr int POOL = 64;
-// Bounded rejection loop of random_unit_vector (shade_step<T, true>, fp64 persistent kernels): rounds a wave runs per
-// iteration before the lanes still without a candidate resume in the next one.  Unbounded in the drain, where a lone
-// chain's latency counts and no other lane waits for the rounds.  Measured on one box against the blocking loop
-// (profiles/r03/r03_ab_carry_over_unit_vector_rounds.jsonl, r03_ab_retry_unit_vector_rounds.jsonl): the main launch issues
-// 5-6 % fewer vector instructions in both precisions and fp64 -- whose round is six XORWOW steps -- renders 5 % faster;
-// fp32 does not: a lane that waits costs its wave a whole iteration's worth of the work every iteration does whatever
-// the lane count (hit_world's set-up and direct list, the shade prologue: half of an iteration), which is what the
-// saved rounds were worth, and small frames and shards, bound by the latency of one chain, lose 2-4 %.  So: fp64 only.
+// Bounded rejection loop of random_unit_vector (shade_step<T, true>): rounds a wave runs per trip before the lanes still without a candidate
+// resume in the next one.  Unbounded in the drain, where a lone chain's latency counts and no other lane waits for the rounds.  fp64 -- whose
+// round is six XORWOW steps -- gains 5 % everywhere (round 3) and always bounds its loop.  fp32 gains where throughput binds and loses where one
+// chain's latency does: round 3 measured -5.6 % vector instructions and no time on the 1080p frame, -2...4 % on small frames and shards; with
+// round 4's shorter trips 1080p gains 1.8 %, 2560 x 1440 4.3 %, 3840 x 2160 2.2 %, 1280 x 720 loses 1-3 % (profiles/r04/ab_bounded_rounds_f32.jsonl,
+// ruv_rounds_sweep.jsonl).  The bound has to be a compile-time constant (the three rounds unroll; as a launch parameter the loop and its two extra
+// registers cost what the bound saves), so the fp32 main launch and prepass exist in both forms (template argument BOUND_F32) and launch_render
+// takes the bounded one when the launch has at least four 64-pixel pools per resident wave.
 #ifndef RTIOW_RUV_ROUNDS_PER_ITERATION
 #define RTIOW_RUV_ROUNDS_PER_ITERATION 3
 #endif
@@ -123,7 +123,7 @@ template <class T> struct alignas(16) PoolArea {
     T dres[2][2][RTIOW_POOL_CAPD];
 };
 
-template <class T, int SRC, bool COUNT, bool SOLO = false>
+template <class T, int SRC, bool COUNT, bool SOLO = false, bool BOUND_F32 = false>
 __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
     const T* lds_geom = stage_scene<T, SRC>(p);
     // per-wave scratch for hit_world_coop, behind the staged tables
@@ -136,14 +136,11 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
     st.acc = {0, 0, 0};
     st.sample = 0; st.depth = 0;
     unsigned int cost = 0;                       // segments of the lane's current pixel in this launch
-#ifndef RTIOW_RUV_BOUNDED_F32
-#define RTIOW_RUV_BOUNDED_F32 0
-#endif
 #ifndef RTIOW_RUV_BOUNDED_F64
 #define RTIOW_RUV_BOUNDED_F64 1
 #endif
     constexpr bool POOLED = RTIOW_POOLED != 0 && !SOLO;
-    constexpr bool RETRY = sizeof(T) == 8 ? RTIOW_RUV_BOUNDED_F64 != 0 : RTIOW_RUV_BOUNDED_F32 != 0;   // see RTIOW_RUV_ROUNDS_PER_ITERATION
+    constexpr bool RETRY = sizeof(T) == 8 ? RTIOW_RUV_BOUNDED_F64 != 0 : BOUND_F32;   // see RTIOW_RUV_ROUNDS_PER_ITERATION
     bool retry = false;                          // RETRY: the lane's rejection loop goes on in this iteration (closest, hit kept)
     T closest = __builtin_huge_val();
     int hit = -1;
@@ -519,10 +516,10 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
 #else
 #define RT_MAIN_OCCUPANCY
 #endif
-template <class T, int SRC, bool COUNT>
-__global__ void __launch_bounds__(1024) RT_MAIN_OCCUPANCY render_persistent_kernel(const RenderParams<T> p) { persistent_body<T, SRC, COUNT>(p); }
-template <class T, int SRC, bool COUNT>
-__global__ void __launch_bounds__(1024) render_prepass_kernel(const RenderParams<T> p) { persistent_body<T, SRC, COUNT>(p); }
+template <class T, int SRC, bool COUNT, bool BOUND_F32 = false>
+__global__ void __launch_bounds__(1024) RT_MAIN_OCCUPANCY render_persistent_kernel(const RenderParams<T> p) { persistent_body<T, SRC, COUNT, false, BOUND_F32>(p); }
+template <class T, int SRC, bool COUNT, bool BOUND_F32 = false>
+__global__ void __launch_bounds__(1024) render_prepass_kernel(const RenderParams<T> p) { persistent_body<T, SRC, COUNT, false, BOUND_F32>(p); }
 // The main launch of a partly filled GPU (small frame, shard of a multi-GPU frame): the same body with the solo
 // waves of ColdParams::solo_* compiled in (a kernel of its own, so that the full-frame launch does not carry the
 // wave-uniform bookkeeping: +1 % measured).

@@ -28,6 +28,15 @@ RenderFn<T> pick_prepass_kernel(bool lds, bool count) {
     if (lds) return count ? (RenderFn<T>)render_prepass_kernel<T, RTIOW_SCENE_LDS, true> : (RenderFn<T>)render_prepass_kernel<T, RTIOW_SCENE_LDS, false>;
     return count ? (RenderFn<T>)render_prepass_kernel<T, RTIOW_SCENE_SCALAR, true> : (RenderFn<T>)render_prepass_kernel<T, RTIOW_SCENE_SCALAR, false>;
 }
+// The fp32 persistent kernels with the bounded rejection loop (render_kernels.h, BOUND_F32); fp64 bounds its loop in every kernel.
+template <class T> RenderFn<T> pick_bounded_kernel(bool prepass, bool lds, bool count) { (void)prepass; (void)lds; (void)count; return nullptr; }
+template <> RenderFn<float> pick_bounded_kernel<float>(bool prepass, bool lds, bool count) {
+#define RT_PICK(K) (lds ? (count ? (RenderFn<float>)K<float, RTIOW_SCENE_LDS, true, true> : (RenderFn<float>)K<float, RTIOW_SCENE_LDS, false, true>) \
+                        : (count ? (RenderFn<float>)K<float, RTIOW_SCENE_SCALAR, true, true> : (RenderFn<float>)K<float, RTIOW_SCENE_SCALAR, false, true>))
+    return prepass ? RT_PICK(render_prepass_kernel) : RT_PICK(render_persistent_kernel);
+#undef RT_PICK
+}
+
 template <class T>
 RenderFn<T> pick_kernel(bool persistent, bool lds, bool count) {
     if (lds) return count ? pick_sched<T, RTIOW_SCENE_LDS, true>(persistent) : pick_sched<T, RTIOW_SCENE_LDS, false>(persistent);
@@ -145,6 +154,24 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             lane_cap = tuned("RTIOW_TUNE_LANE_CAP", lane_cap);
         }
         p.lane_cap = lane_cap;
+        // fp32: the bounded rejection loop where throughput binds -- at least four pools per resident wave (1080p: 6.3; 1280 x 720, shards and small
+        // frames end with one chain's latency and keep the blocking loop) -- if that kernel keeps the occupancy this launch was sized for
+        bool bounded_f32 = false;
+        if (sizeof(T) == 4 && h->schedule != RTIOW_SCHED_STATIC) {
+            const long long pools = tile_slots / POOL, waves = (long long)h->num_cus * per_cu * waves_per_block;
+#ifdef RTIOW_TUNING
+            const bool want = tuned("RTIOW_TUNE_RUV_BOUNDED", pools >= 4 * waves ? 1 : 0) != 0;
+#else
+            const bool want = pools >= 4 * waves;
+#endif
+            if (want) {
+                RenderFn<T> kb = pick_bounded_kernel<T>(false, lds_source, seg_counter != nullptr);
+                if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                int per_cu_b = 0;
+                HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, (const void*)kb, threads, lds));
+                if (per_cu_b >= per_cu) { k = kb; bounded_f32 = true; HIP_TRY(h, hipFuncGetAttributes(&fa, (const void*)k)); }
+            }
+        }
         long long blocks = (long long)h->num_cus * per_cu;
         const long long per_block = (long long)waves_per_block * lane_cap;
         const long long useful = (tile_slots + per_block - 1) / per_block;
@@ -214,7 +241,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             RenderParams<T> pa = p;
             pa.s_end = SA; pa.cold.mid_out = h->mid; pa.cold.cost_out = h->cost;
             pa.cold.seg_counter = seg_counter;
-            RenderFn<T> kp = pick_prepass_kernel<T>(lds_source, seg_counter != nullptr);
+            RenderFn<T> kp = bounded_f32 ? pick_bounded_kernel<T>(true, lds_source, seg_counter != nullptr) : pick_prepass_kernel<T>(lds_source, seg_counter != nullptr);
             if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kp, grid, block, lds, h->stream, pa);
             if (h->time_phases) HIP_TRY(h, hipEventRecord(h->ev_a, h->stream));

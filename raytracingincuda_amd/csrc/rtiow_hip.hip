@@ -149,7 +149,7 @@ int rtiow_create(int device, int precision, rtiow_handle* out) {
             (void)hipMemcpy(host.data(), warm, host.size(), hipMemcpyDeviceToHost);
             (void)hipFree(warm);
         }
-        if (precision == 32) (void)hipFuncGetAttributes(&fa, (const void*)render_persistent_kernel<float, RTIOW_SCENE_LDS, false>);
+        if (precision == 32) (void)hipFuncGetAttributes(&fa, (const void*)render_persistent_kernel<float, RTIOW_SCENE_LDS, false, true>);
         else (void)hipFuncGetAttributes(&fa, (const void*)render_persistent_kernel<double, RTIOW_SCENE_LDS, false>);
         (void)hipGetLastError();
     }

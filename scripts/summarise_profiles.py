@@ -27,7 +27,8 @@ rows = list(csv.DictReader(open(stats)))
 def row(part):
     hit = [r for r in rows if part in r["Name"]]
     return hit[0] if hit else None
-main, pre, place = row("render_persistent_kernel<float, 0, false>"), row("render_prepass_kernel<float, 0, false>"), row("place_pixels_kernel<float>")
+# (the fp32 kernels exist with and without the bounded rejection loop -- fourth template argument -- and a launch uses one of them)
+main, pre, place = row("render_persistent_kernel<float, 0, false"), row("render_prepass_kernel<float, 0, false"), row("place_pixels_kernel<float>")
 agree = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-scaling-probe --pmc off",
          "rocprof_main_launch_avg_ms": float(main["AverageNs"]) / 1e6, "rocprof_main_launch_calls": int(main["Calls"]),
          "bench_roofline_launch_ms_mean": b["roofline"]["launch_ms_mean"],

@@ -31,8 +31,8 @@ def test_counter_tree_is_reduced_per_launch_class(tmp_path):
     rows = ["Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp"]
     def row(disp, kernel, counter, value):
         rows.append('%d,%d,1,1,1,1,1,1,"%s",256,0,0,88,0,106,%s,%s,0,1' % (disp, disp, kernel, counter, value))
-    main = "void (anonymous namespace)::render_persistent_kernel<float, 0, false>((anonymous namespace)::RenderParams<float>)"
-    pre = "void (anonymous namespace)::render_prepass_kernel<float, 0, false>((anonymous namespace)::RenderParams<float>)"
+    main = "void (anonymous namespace)::render_persistent_kernel<float, 0, false, true>((anonymous namespace)::RenderParams<float>)"
+    pre = "void (anonymous namespace)::render_prepass_kernel<float, 0, false, true>((anonymous namespace)::RenderParams<float>)"
     for disp, v in ((1, 100.0), (5, 300.0)):                 # two dispatches of the main launch; one of them reported in two rows (dimension instances)
         row(disp, main, "SQ_INSTS_VALU", v)
     row(5, main, "SQ_INSTS_VALU", 50.0)
