@@ -192,9 +192,19 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
         cz = cz < 0 ? 0 : (cz >= g.nz ? g.nz - 1 : cz);
         const bool step_x = __builtin_fabsf(dx) >= 1e-30f, step_z = __builtin_fabsf(dz) >= 1e-30f;
         const int sx = dx > 0.0f ? 1 : -1, sz = dz > 0.0f ? 1 : -1;
+#ifdef RTIOW_PATH_STATS
+        int step_no = 0;                                   // which step of its walk the wave is in (instrumented build: profiles/r04/path_stats_walk_steps*.json)
+        if (walking) PATH_STAT(PS_WALK);
+#endif
         while (__builtin_amdgcn_ballot_w64(walking) != 0) {
+#ifdef RTIOW_PATH_STATS
+            ++step_no;
+#endif
             if (walking) {
                 PATH_STAT(PS_GRID_STEP);
+#ifdef RTIOW_PATH_STATS
+                path_stat(step_no == 1 ? PS_STEP_1 : step_no == 2 ? PS_STEP_2 : step_no == 3 ? PS_STEP_3 : step_no == 4 ? PS_STEP_4 : step_no <= 8 ? PS_STEP_5_8 : PS_STEP_9_UP);
+#endif
                 const uint2 rec = cells[cz * g.nx + cx];
                 if (rec.x != 0xffffffffu) cell_tests<T>(aos, rec.x, rec.y, O, D, a, closest, hit, fdc);
                 // the parameter at which the ray leaves this cell, per axis
