@@ -110,21 +110,27 @@ def host_cpu():
 
 
 def cpu_baseline(args):
-    """Reference serial tracer on a bounded sample: the same scene, camera, spp and bounces
-    on a 1/16-area frame (W/4 x H/4), 1 thread.  ~10-30 s of CPU work."""
-    W, H = max(args.width // 4, 16), max(args.height // 4, 9)
-    S, B = args.samples, args.bounces
+    """Reference serial tracer on a bounded sample OF THE BENCHMARK FRAME ITSELF: every 16th row of the W x H view (same scene, camera, spp and
+    bounces: 1/16 of the frame's rays, rows spread over sky, spheres and ground), 1 thread.  ~10 s of CPU work.  Without oracle/_ref: the
+    oracle's serial port on the view at 1/4 linear resolution (the same number of rays)."""
+    W, H, S, B = args.width, args.height, args.samples, args.bounces
+    step = 16
     drv = os.path.join(ROOT, "oracle", "_ref", "ref_serial_driver")
+    if os.path.exists(drv) and H >= step:
+        rows = len(range(step // 2, H, step))
+        rays = W * rows * S
+        t0 = time.perf_counter()
+        r = subprocess.run([drv, str(args.scene_id), str(W), str(H), str(S), str(B), str(step)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        dt = time.perf_counter() - t0
+        if r.returncode == 0 and r.stdout.startswith(b"P3"):
+            sample = "scene %d, every %dth row of the %dx%d benchmark view itself (%d rows = 1/%d of its rays), %d spp, depth %d, serial fp64" % (
+                args.scene_id, step, W, H, rows, step, S, B)
+            return dict({"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
+                         "sample": sample + "; reference src/InOneWeekend headers built by oracle/Makefile (oracle/ref_serial_driver.cc, row mode)", "seconds": dt}, **host_cpu())
+    W, H = max(args.width // 4, 16), max(args.height // 4, 9)
     sample = "scene %d, %dx%d (the %dx%d view at 1/4 linear resolution), %d spp, depth %d, serial fp64" % (
         args.scene_id, W, H, args.width, args.height, S, B)
     rays = W * H * S
-    if os.path.exists(drv):
-        t0 = time.perf_counter()
-        r = subprocess.run([drv, str(args.scene_id), str(W), str(H), str(S), str(B)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
-        dt = time.perf_counter() - t0
-        if r.returncode == 0 and r.stdout.startswith(b"P3"):
-            return dict({"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
-                         "sample": sample + "; reference src/InOneWeekend headers built by oracle/Makefile", "seconds": dt}, **host_cpu())
     from tests.oracle_lib import Oracle   # the oracle is only ever the checker / CPU baseline
     orc = Oracle()
     t0 = time.perf_counter()

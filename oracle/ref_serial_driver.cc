@@ -7,9 +7,15 @@
 // src/GlobalFloatCUDAInOneWeekend/main.cu:148-284.  Every class used (camera, sphere,
 // hittable_list, lambertian, metal, dielectric, vec3, ...) is the reference's.
 //
-//   ref_serial_driver <scene_id> <width> <height> <samples> <depth>   -> P3 on stdout
+//   ref_serial_driver <scene_id> <width> <height> <samples> <depth>              -> P3 on stdout
+//   ref_serial_driver <scene_id> <width> <height> <samples> <depth> <row_step>   -> the rows row_step/2, row_step/2 + row_step, ... of the SAME
+//       view only (bench.py's bounded CPU sample of the benchmark frame itself): the reference's own initialize / get_ray / ray_color /
+//       write_color called row by row -- those members are private to its camera class, hence the access define below; the header reads
+//       "P3 / width rows / 255".  The random stream of a row subset is not the full render's, which a throughput sample does not need.
 #include "rtweekend.h"
+#define private public
 #include "camera.h"
+#undef private
 #include "hittable.h"
 #include "hittable_list.h"
 #include "material.h"
@@ -19,7 +25,8 @@
 #include <cstdlib>
 
 int main(int argc, char** argv) {
-    if (argc != 6) { std::fprintf(stderr, "usage: %s scene_id width height samples depth\n", argv[0]); return 2; }
+    if (argc != 6 && argc != 7) { std::fprintf(stderr, "usage: %s scene_id width height samples depth [row_step]\n", argv[0]); return 2; }
+    const int row_step = argc == 7 ? std::atoi(argv[6]) : 0;
     const int scene_id = std::atoi(argv[1]), W = std::atoi(argv[2]), H = std::atoi(argv[3]);
     const int S = std::atoi(argv[4]), depth = std::atoi(argv[5]);
     int a0, a1, b0, b1;
@@ -67,6 +74,16 @@ int main(int argc, char** argv) {
     // camera::initialize derives the height as int(width / aspect_ratio)
     // (src/InOneWeekend/camera.h:69); refuse sizes where that does not give back H.
     if (int(W / cam.aspect_ratio) != H) { std::fprintf(stderr, "height %d not representable via aspect ratio\n", H); return 3; }
-    cam.render(world);
+    if (row_step <= 0) { cam.render(world); return 0; }
+    cam.initialize();
+    int rows = 0;
+    for (int j = row_step / 2; j < cam.image_height; j += row_step) ++rows;
+    std::cout << "P3\n" << cam.image_width << ' ' << rows << "\n255\n";
+    for (int j = row_step / 2; j < cam.image_height; j += row_step)
+        for (int i = 0; i < cam.image_width; i++) {
+            color pixel_color(0, 0, 0);
+            for (int sample = 0; sample < cam.samples_per_pixel; sample++) pixel_color += cam.ray_color(cam.get_ray(i, j), cam.max_depth, world, j, i);
+            write_color(std::cout, cam.pixel_samples_scale * pixel_color);
+        }
     return 0;
 }
