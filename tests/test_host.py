@@ -231,3 +231,12 @@ def test_bench_refuses_to_run_without_a_gpu():
     from tests.conftest import ROOT
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout) and not r.stdout.strip().startswith("{")
+
+
+def test_renderer_group_documents_the_rccl_banner_on_stdout(native):
+    """the library no longer redirects fd 1 around ncclCommInitAll, so a caller whose stdout is data has to know that RCCL prints its
+    version banner there -- RendererGroup says so and offers quiet_stdout."""
+    import inspect
+    doc = native.RendererGroup.__doc__
+    assert "RCCL" in doc and "stdout" in doc.lower() and "quiet_stdout" in doc
+    assert "quiet_stdout" in inspect.signature(native.RendererGroup.__init__).parameters
