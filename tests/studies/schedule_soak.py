@@ -2,7 +2,9 @@
 scenes, precisions and shards through the default sorted schedule (prepass, cost sort, main launch; solo waves on a
 partly filled GPU) against the static schedule (one lane per pixel, no hand-out), bit for bit.  A hand-out bug --
 a slot skipped, handed out twice, a state parked or unparked wrongly -- changes the image.  Prints one line per case;
-exits non-zero on the first mismatch.      python tests/studies/schedule_soak.py [n_cases]"""
+exits non-zero on the first mismatch.      python tests/studies/schedule_soak.py [n_cases] [--large]
+--large: frames of 1.4-3 M pixels, unsharded -- at least four 64-pixel pools per resident wave, where the fp32 launches take the kernels with
+the bounded rejection loop (render_persistent_kernel<float, SRC, COUNT, true>; launch_render)."""
 import os
 import sys
 
@@ -12,7 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import raytracingincuda_amd as rt  # noqa: E402
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+large = "--large" in sys.argv
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n_cases = int(args[0]) if args else 60
 rng = np.random.default_rng(77)
 solo_cases = plain_cases = unsorted_cases = 0
 for case in range(n_cases):
@@ -20,10 +24,12 @@ for case in range(n_cases):
     scene = int(rng.choice([1, 2, 3]))
     W = int(rng.integers(33, 1400)); H = int(rng.integers(17, 800))
     S = int(rng.choice([3, 23, 24, 25, 40, 64, 70])); B = int(rng.choice([1, 5, 25, 32, 33, 50]))
-    if W * H * S > 6e7:
-        S = max(24, int(6e7 / (W * H)))
+    if large:
+        W = int(rng.integers(1500, 2400)); H = int(rng.integers(950, 1300)); S = int(rng.choice([24, 25, 40]))
+    if W * H * S > (1.3e8 if large else 6e7):
+        S = max(24, int((1.3e8 if large else 6e7) / (W * H)))
     shard = None
-    if case % 2:
+    if case % 2 and not large:
         n = int(rng.integers(2, 9))
         shard = (int(rng.integers(0, n)), n, int(rng.choice([1, 2, 3, 8])))
     sc = rt.build_scene(scene, prec)
