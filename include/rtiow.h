@@ -62,7 +62,9 @@ extern "C" {
  * records their path-segment counts; the pixels are then ranked heavy-first into balanced pools
  * of neighbouring pixels and the main launch renders the remaining samples in that order (RNG
  * state and colour sum carried exactly, so the image is unchanged).  Removes the drain tail of
- * late heavy pixels.  Default. */
+ * late heavy pixels.  Default.  The hand-out order packs a pixel as (local row << 16 | column): a frame wider than 65535
+ * columns or a shard taller than 32767 rows (or smaller than 4096 pixels) is rendered like RTIOW_SCHED_PERSISTENT, in one
+ * launch in tile order (same image; rtiow_stats.phases then reads 1). */
 #define RTIOW_SCHED_SORTED     2
 
 typedef struct rtiow_handle_s* rtiow_handle;

@@ -44,8 +44,10 @@ int rtiow_debug_grid_plan(int n, const double* center_radius, const double* cent
 
 /* Test hook, host only (no GPU, no RCCL): the exchange's schedule -- the very function rtiow_group_gather runs --
  * against a recording table instead of HIP / RCCL, for n ranks on `devices` with `rows` local rows each.
- * mode = RTIOW_GATHER_RCCL | RTIOW_GATHER_PEER.  One record of 8 int64 per call (layout: csrc/rtiow_group.hip);
- * fail_at >= 0 makes that call fail.  Returns the number of records; *schedule_rc = what the schedule returned. */
+ * mode = RTIOW_GATHER_RCCL, RTIOW_GATHER_PEER or RTIOW_GATHER_HOST, optionally | 0x100: with the fallback chain of RTIOW_GATHER_AUTO
+ * (RCCL -> peer copies -> host-staged copies; the last record is then {12, -, the transport that carried the image}).  One record of
+ * 8 int64 per call (layout: csrc/rtiow_group.hip); fail_at >= 0 makes that call fail.  Returns the number of records;
+ * *schedule_rc = what the schedule returned. */
 int rtiow_debug_gather_schedule(int n, const int* devices, const int* rows, int W, int precision, int mode, int fail_at,
                                 int64_t* records, size_t cap_records, int* schedule_rc);
 

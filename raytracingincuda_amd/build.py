@@ -25,8 +25,10 @@ BIN = os.path.join(PKG, "bin")
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
-    "-fno-fast-math", "-I" + INC,
+    "-fno-fast-math", "-fvisibility-inlines-hidden", "-I" + INC,
 ]
+# the export list: rtiow_* only (csrc/librtiow_hip.map)
+HIP_LINK = ["-Wl,--version-script=" + os.path.join(CSRC, "librtiow_hip.map"), "-ldl"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-I" + INC]
 
 
@@ -66,6 +68,7 @@ def hip_build_id(extra_flags=()):
         h.update(b"\0")
     flags = [f for f in HIP_FLAGS if not f.startswith("-I")] + list(extra_flags)
     h.update(" ".join(flags).encode())
+    h.update(open(os.path.join(CSRC, "librtiow_hip.map"), "rb").read())
     return h.hexdigest()
 
 
@@ -80,7 +83,7 @@ def build_stats(verbose=True):
     (lib/librtiow_hip_stats.so, -DRTIOW_PATH_STATS; used by scripts/path_stats_probe.py only)."""
     os.makedirs(LIB, exist_ok=True)
     out = os.path.join(LIB, "librtiow_hip_stats.so")
-    _run([_hipcc()] + HIP_FLAGS + ["-DRTIOW_PATH_STATS", "-DRTIOW_DEBUG_API", '-DRTIOW_BUILD_ID="%s"' % hip_build_id(["-DRTIOW_PATH_STATS", "-DRTIOW_DEBUG_API"]), "-o", out, os.path.join(CSRC, "rtiow_hip.hip"), os.path.join(CSRC, "rtiow_group.hip"), "-ldl"], verbose)
+    _run([_hipcc()] + HIP_FLAGS + ["-DRTIOW_PATH_STATS", "-DRTIOW_DEBUG_API", '-DRTIOW_BUILD_ID="%s"' % hip_build_id(["-DRTIOW_PATH_STATS", "-DRTIOW_DEBUG_API"]), "-o", out, os.path.join(CSRC, "rtiow_hip.hip"), os.path.join(CSRC, "rtiow_group.hip")] + HIP_LINK, verbose)
     return out
 
 
@@ -92,7 +95,7 @@ def build_variant(name, defines=(), csrc=None, verbose=True):
     src = csrc or CSRC
     out = os.path.join(out_dir, name + ".so")
     flags = [f for f in HIP_FLAGS if not f.startswith("-I")] + ["-I" + (os.path.join(os.path.dirname(os.path.dirname(src)), "include") if csrc else INC)]
-    _run([_hipcc()] + flags + list(defines) + ['-DRTIOW_BUILD_ID="variant:%s"' % name, "-o", out, os.path.join(src, "rtiow_hip.hip"), os.path.join(src, "rtiow_group.hip"), "-ldl"], verbose)
+    _run([_hipcc()] + flags + list(defines) + ['-DRTIOW_BUILD_ID="variant:%s"' % name, "-o", out, os.path.join(src, "rtiow_hip.hip"), os.path.join(src, "rtiow_group.hip")] + HIP_LINK, verbose)
     return out
 
 
@@ -104,13 +107,13 @@ def build(force=False, verbose=True):
 
     hip_srcs = [os.path.join(CSRC, "rtiow_hip.hip"), os.path.join(CSRC, "rtiow_group.hip")]
     hip_so = os.path.join(LIB, "librtiow_hip.so")
-    if force or _newer(hip_so, hip_srcs + hip_includes() + [me] + headers):
+    if force or _newer(hip_so, hip_srcs + hip_includes() + [me, os.path.join(CSRC, "librtiow_hip.map")] + headers):
         # librccl is NOT linked: rtiow_group.hip dlopens it on first use (-ldl for old glibc)
-        _run([_hipcc()] + HIP_FLAGS + ['-DRTIOW_BUILD_ID="%s"' % hip_build_id(), "-o", hip_so] + hip_srcs + ["-ldl"], verbose)
+        _run([_hipcc()] + HIP_FLAGS + ['-DRTIOW_BUILD_ID="%s"' % hip_build_id(), "-o", hip_so] + hip_srcs + HIP_LINK, verbose)
     # the test build: the same kernels + the hooks of include/rtiow_debug.h (same flags, so the kernels are the product's; its build id names the extra define)
     dbg_so = os.path.join(LIB, "librtiow_hip_debug.so")
-    if force or _newer(dbg_so, hip_srcs + hip_includes() + [me] + headers):
-        _run([_hipcc()] + HIP_FLAGS + ["-DRTIOW_DEBUG_API", '-DRTIOW_BUILD_ID="%s"' % hip_build_id(["-DRTIOW_DEBUG_API"]), "-o", dbg_so] + hip_srcs + ["-ldl"], verbose)
+    if force or _newer(dbg_so, hip_srcs + hip_includes() + [me, os.path.join(CSRC, "librtiow_hip.map")] + headers):
+        _run([_hipcc()] + HIP_FLAGS + ["-DRTIOW_DEBUG_API", '-DRTIOW_BUILD_ID="%s"' % hip_build_id(["-DRTIOW_DEBUG_API"]), "-o", dbg_so] + hip_srcs + HIP_LINK, verbose)
 
     host_src = os.path.join(CSRC, "host", "rtiow_host.cpp")
     host_so = os.path.join(LIB, "librtiow_host.so")

@@ -95,34 +95,6 @@ __device__ __forceinline__ bool tile_slot_pixel(const COLD& c, int slot, int& i,
     return i < c.W && jl < c.local_rows;
 }
 
-
-// The pooled loop's LDS area (persistent_body; it lies where the drain's CoopSlots lie: the two never run together).
-#ifndef RTIOW_POOLED
-#define RTIOW_POOLED 0
-#endif
-#ifndef RTIOW_POOL_NOSERVICE
-#define RTIOW_POOL_NOSERVICE 0   // experiment builds: 1 = the rotated loop alone (no posting, no barriers), 2 = no posting, one barrier per trip
-#endif
-#ifndef RTIOW_POOL_KR
-#define RTIOW_POOL_KR 2          // rounds of random_unit_vector a lane runs itself before it posts its generator
-#endif
-#ifndef RTIOW_POOL_KD
-#define RTIOW_POOL_KD 1          // the same for the lens disk
-#endif
-#ifndef RTIOW_POOL_CAPR
-#define RTIOW_POOL_CAPR 64       // posted unit-vector loops per workgroup and trip (more: the lane loops itself)
-#endif
-#ifndef RTIOW_POOL_CAPD
-#define RTIOW_POOL_CAPD 32
-#endif
-template <class T> struct alignas(16) PoolArea {
-    unsigned ctl[4];                                  // per trip (mod 4): posted unit-vector loops | disk loops << 12 | exhausted waves << 24
-    uint32_t rs[2][6][RTIOW_POOL_CAPR];               // [trip parity][generator word][slot]
-    T rres[2][3][RTIOW_POOL_CAPR];
-    uint32_t ds[2][6][RTIOW_POOL_CAPD];
-    T dres[2][2][RTIOW_POOL_CAPD];
-};
-
 template <class T, int SRC, bool COUNT, bool SOLO = false, bool BOUND_F32 = false>
 __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
     const T* lds_geom = stage_scene<T, SRC>(p);
@@ -139,7 +111,6 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
 #ifndef RTIOW_RUV_BOUNDED_F64
 #define RTIOW_RUV_BOUNDED_F64 1
 #endif
-    constexpr bool POOLED = RTIOW_POOLED != 0 && !SOLO;
     constexpr bool RETRY = sizeof(T) == 8 ? RTIOW_RUV_BOUNDED_F64 != 0 : BOUND_F32;   // see RTIOW_RUV_ROUNDS_PER_ITERATION
     bool retry = false;                          // RETRY: the lane's rejection loop goes on in this iteration (closest, hit kept)
     T closest = __builtin_huge_val();
@@ -240,173 +211,6 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
         }
     };
 
-
-    // ---- The pooled loop (RTIOW_POOLED builds; main launch and prepass of full launches).  The loop is rotated so that the two
-    // rejection loops of a trip stand side by side -- hit_world, shade_front, accumulate + refill, then the SAMPLING STEP
-    // (camera.h:145-146 jitter + vec3.h:109-115 lens disk for the lanes that start a sample, vec3.h:117-125 for the lanes that
-    // scatter diffusely), then shade_back / primary_finish -- and the sampling step pools the workgroup's stragglers: a lane runs
-    // RTIOW_POOL_KR / RTIOW_POOL_KD rounds itself; lanes still without a candidate post their generator in LDS, ONE wave of the
-    // workgroup finishes all posted unit-vector loops and ONE all posted disk loops (64 lanes busy instead of a wave looping for
-    // its own last lane), two workgroup barriers, and the owners take generator and candidate back.  A pixel's draws and their
-    // order are unchanged.  The loop ends for the whole workgroup in the trip in which one of its waves finds the work counter
-    // exhausted; the drain below (no barriers, cooperative hit_world) takes over with the same lane state.
-    if (POOLED && p.lane_cap == 64 && (blockDim.x & 63u) == 0 && blockDim.x == 256) {
-        PoolArea<T>* pool = reinterpret_cast<PoolArea<T>*>(smem_raw + p.coop_offset);
-        const int wave = (int)(threadIdx.x >> 6);
-        const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        if (threadIdx.x < 4) pool->ctl[threadIdx.x] = 0;
-        __syncthreads();
-        const bool defocus = !((T)cam_of(p).defocus_angle <= (T)0);
-        // camera.h:160-171 for a lane whose path has ended
-#define RT_END_SAMPLE() do { \
-            ++st.sample; \
-            st.depth = 0; \
-            if (st.sample < S) fresh = true; \
-            else { \
-                PATH_STAT(PS_FINISH_PIXEL); \
-                const auto& c_ = cold_of(p); \
-                if (COUNT) atomicMax(c_.seg_counter + 2, (unsigned long long)cost); \
-                finish_pixel<T>(c_, lp, st, cost); alive = false; \
-            } } while (0)
-        for (unsigned iter = 0;; ++iter) {
-            // ---- hit_world (camera.h:84-88) for every lane that holds a ray
-            if (alive) PATH_STAT(PS_ITERATION);
-            const bool has_ray = alive && !fresh;
-            const bool need_hit = has_ray && st.depth < p.B;
-            closest = __builtin_huge_val(); hit = -1;
-            if (COUNT) ++it_normal;
-            if (need_hit) {
-                const T a = dot3(st.D, st.D);
-                hit_world<T, SRC>(p, lds_geom, st.O, st.D, a, closest, hit);
-            }
-            // ---- sky / hit record / dielectric; lambertian and metal stop in front of random_unit_vector
-            bool need_ruv = false;
-            ShadeCarry<T> sc;
-            sc.nrm = {0, 0, 0}; sc.fuzz = 0; sc.mtype = 0;
-            if (has_ray) {
-                V3<T> col = {0, 0, 0};
-                bool terminated = true;                                              // camera.h:127 at the depth limit
-                if (need_hit) {
-                    ++cost; if (COUNT) ++nseg;
-                    const int r = shade_front<T>(p, lds_shade, st, closest, hit, col, sc);
-                    terminated = r == SF_TERMINATED;
-                    need_ruv = r == SF_NEED_RUV;
-                }
-                if (terminated) {
-                    st.acc = {st.acc.x + col.x, st.acc.y + col.y, st.acc.z + col.z};   // camera.h:160
-                    RT_END_SAMPLE();
-                }
-            }
-            refill();
-            // ---- the sampling step, first the rounds every lane runs itself
-            T jox = 0, joy = 0, px = 0, py = 0;
-            bool need_disk = false;
-            const bool starts = alive && fresh;
-            if (starts) {
-                PATH_STAT(PS_GEN_PRIMARY);
-                primary_jitter<T>(st.rs, jox, joy);
-                if (defocus) need_disk = !disk_rounds<T>(st.rs, RTIOW_POOL_KD, px, py);
-            }
-            T ux = 0, uy = 0, uz = 0;
-            bool more_ruv = false;
-            if (need_ruv) {
-                PATH_STAT(PS_RUV_CALL);
-                T ul;
-                more_ruv = !random_unit_vector_rounds<T>(st.rs, RTIOW_POOL_KR, ux, uy, uz, ul);
-            }
-            // ---- stragglers post their generators: one LDS atomic per wave reserves the slots of both lists
-#if RTIOW_POOL_NOSERVICE
-            if (more_ruv) { ruv_candidate<T>(st.rs, ux, uy, uz); more_ruv = false; }
-            if (need_disk) { disk_candidate<T>(st.rs, px, py); need_disk = false; }
-#endif
-            const unsigned long long m_r = __builtin_amdgcn_ballot_w64(more_ruv), m_d = __builtin_amdgcn_ballot_w64(need_disk);
-            const unsigned add = (unsigned)__builtin_popcountll(m_r) | ((unsigned)__builtin_popcountll(m_d) << 12) | (exhausted ? 1u << 24 : 0u);
-            unsigned base = 0;
-            if (add != 0) {
-                if (lane == 0) base = atomicAdd(&pool->ctl[iter & 3u], add);
-                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            }
-            const int buf = (int)(iter & 1u);
-            int pos = 0;
-            if (more_ruv) {
-                pos = (int)(base & 0xfffu) + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_r >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_r, 0u));
-                if (pos < RTIOW_POOL_CAPR) {
-                    pool->rs[buf][0][pos] = st.rs.v0; pool->rs[buf][1][pos] = st.rs.v1; pool->rs[buf][2][pos] = st.rs.v2;
-                    pool->rs[buf][3][pos] = st.rs.v3; pool->rs[buf][4][pos] = st.rs.v4; pool->rs[buf][5][pos] = st.rs.d;
-                } else { ruv_candidate<T>(st.rs, ux, uy, uz); more_ruv = false; }   // list full: the lane finishes its own loop
-            }
-            if (need_disk) {
-                pos = (int)((base >> 12) & 0xfffu) + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_d >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_d, 0u));
-                if (pos < RTIOW_POOL_CAPD) {
-                    pool->ds[buf][0][pos] = st.rs.v0; pool->ds[buf][1][pos] = st.rs.v1; pool->ds[buf][2][pos] = st.rs.v2;
-                    pool->ds[buf][3][pos] = st.rs.v3; pool->ds[buf][4][pos] = st.rs.v4; pool->ds[buf][5][pos] = st.rs.d;
-                } else { disk_candidate<T>(st.rs, px, py); need_disk = false; }
-            }
-#if RTIOW_POOL_NOSERVICE == 1
-            const unsigned w = exhausted ? 1u << 24 : 0u;
-#else
-            __syncthreads();
-            const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)pool->ctl[iter & 3u]);
-#endif
-            if (threadIdx.x == 0) pool->ctl[(iter + 2u) & 3u] = 0;      // next written two trips from now, last read one trip ago
-            int n_r = (int)(w & 0xfffu), n_d = (int)((w >> 12) & 0xfffu);
-            n_r = n_r < RTIOW_POOL_CAPR ? n_r : RTIOW_POOL_CAPR;
-            n_d = n_d < RTIOW_POOL_CAPD ? n_d : RTIOW_POOL_CAPD;
-            const bool leave = (w >> 24) != 0;
-            if (n_r + n_d != 0) {                                           // the same for every wave of the workgroup
-                // ---- the sampling service: batches of 64 posted loops, dealt to the waves in turn
-                const int b_r = (n_r + 63) >> 6, b_d = (n_d + 63) >> 6;
-                for (int b = (wave - (int)(iter & 3u)) & 3; b < b_r + b_d; b += 4) {
-                    if (b < b_r) {
-                        const int e = b * 64 + lane;
-                        if (e < n_r) {
-                            Rng s;
-                            s.v0 = pool->rs[buf][0][e]; s.v1 = pool->rs[buf][1][e]; s.v2 = pool->rs[buf][2][e];
-                            s.v3 = pool->rs[buf][3][e]; s.v4 = pool->rs[buf][4][e]; s.d = pool->rs[buf][5][e];
-                            T x, y, z;
-                            ruv_candidate<T>(s, x, y, z);
-                            pool->rs[buf][0][e] = s.v0; pool->rs[buf][1][e] = s.v1; pool->rs[buf][2][e] = s.v2;
-                            pool->rs[buf][3][e] = s.v3; pool->rs[buf][4][e] = s.v4; pool->rs[buf][5][e] = s.d;
-                            pool->rres[buf][0][e] = x; pool->rres[buf][1][e] = y; pool->rres[buf][2][e] = z;
-                        }
-                    } else {
-                        const int e = (b - b_r) * 64 + lane;
-                        if (e < n_d) {
-                            Rng s;
-                            s.v0 = pool->ds[buf][0][e]; s.v1 = pool->ds[buf][1][e]; s.v2 = pool->ds[buf][2][e];
-                            s.v3 = pool->ds[buf][3][e]; s.v4 = pool->ds[buf][4][e]; s.d = pool->ds[buf][5][e];
-                            T x, y;
-                            disk_candidate<T>(s, x, y);
-                            pool->ds[buf][0][e] = s.v0; pool->ds[buf][1][e] = s.v1; pool->ds[buf][2][e] = s.v2;
-                            pool->ds[buf][3][e] = s.v3; pool->ds[buf][4][e] = s.v4; pool->ds[buf][5][e] = s.d;
-                            pool->dres[buf][0][e] = x; pool->dres[buf][1][e] = y;
-                        }
-                    }
-                }
-                __syncthreads();
-                if (more_ruv) {
-                    st.rs.v0 = pool->rs[buf][0][pos]; st.rs.v1 = pool->rs[buf][1][pos]; st.rs.v2 = pool->rs[buf][2][pos];
-                    st.rs.v3 = pool->rs[buf][3][pos]; st.rs.v4 = pool->rs[buf][4][pos]; st.rs.d = pool->rs[buf][5][pos];
-                    ux = pool->rres[buf][0][pos]; uy = pool->rres[buf][1][pos]; uz = pool->rres[buf][2][pos];
-                }
-                if (need_disk) {
-                    st.rs.v0 = pool->ds[buf][0][pos]; st.rs.v1 = pool->ds[buf][1][pos]; st.rs.v2 = pool->ds[buf][2][pos];
-                    st.rs.v3 = pool->ds[buf][3][pos]; st.rs.v4 = pool->ds[buf][4][pos]; st.rs.d = pool->ds[buf][5][pos];
-                    px = pool->dres[buf][0][pos]; py = pool->dres[buf][1][pos];
-                }
-            }
-            // ---- what follows the rejection loops
-            if (starts) {
-                primary_finish<T>(p, i, j, jox, joy, defocus, px, py, st.O, st.D, st.sky_uy);
-                st.atten = {1, 1, 1};
-                fresh = false;
-            }
-            if (need_ruv) {
-                if (!shade_back<T>(st, sc, ux, uy, uz)) RT_END_SAMPLE();      // the metal absorbed the ray: black (camera.h:117)
-            }
-            if (leave) { if (RTIOW_POOL_NOSERVICE != 1) __syncthreads(); break; }                         // the pool area is the drain's scratch from here on
-        }
-    }
     for (;;) {
         REGION_BEGIN(total);
         REGION_BEGIN(refill);

@@ -44,65 +44,6 @@ template <class T> __device__ __forceinline__ bool random_unit_vector_rounds(Rng
     return false;
 }
 
-// ---- the same pieces, cut at the rejection loops (pooled loop of persistent_body, render_kernels.h): a lane runs a bounded
-// number of rounds itself, the lanes still without a candidate hand their generator to the workgroup's sampling service,
-// which finishes the loop (ruv_candidate / disk_candidate) and hands generator and candidate back.  Same draws in the same
-// order per pixel, same arithmetic on the accepted candidate.
-template <class T> __device__ __forceinline__ void ruv_candidate(Rng& s, T& x, T& y, T& z) {      // vec3.h:117-125: the loop without the normalisation
-    for (;;) {
-        PATH_STAT(PS_RUV_ROUND);
-        T u0, u1, u2;
-        Real<T>::uniform3(s, u0, u1, u2);
-        x = RT_FMA(u0, (T)2, (T)-1);
-        y = RT_FMA(u1, (T)2, (T)-1);
-        z = RT_FMA(u2, (T)2, (T)-1);
-        const T lensq = RT_FMA(z, z, RT_FMA(y, y, x * x));
-        if (Real<T>::ruv_eps < lensq && lensq <= (T)1) break;
-    }
-}
-template <class T> __device__ __forceinline__ bool disk_rounds(Rng& s, int rounds, T& px, T& py) {   // vec3.h:109-115, at most `rounds` rounds
-    for (int r = 0; r < rounds; ++r) {
-        PATH_STAT(PS_DISK_ROUND);
-        T u0, u1;
-        Real<T>::uniform2(s, u0, u1);
-        px = RT_FMA((T)2, u0, (T)-1);
-        py = RT_FMA((T)2, u1, (T)-1);
-        if (RT_FMA(py, py, px * px) < (T)1) return true;
-    }
-    return false;
-}
-template <class T> __device__ __forceinline__ void disk_candidate(Rng& s, T& px, T& py) {
-    for (;;) {
-        PATH_STAT(PS_DISK_ROUND);
-        T u0, u1;
-        Real<T>::uniform2(s, u0, u1);
-        px = RT_FMA((T)2, u0, (T)-1);
-        py = RT_FMA((T)2, u1, (T)-1);
-        if (RT_FMA(py, py, px * px) < (T)1) break;
-    }
-}
-// camera.h:145-146 (the two jitter draws, first argument first) and camera.h:147-155 once the lens sample is known.
-template <class T> __device__ __forceinline__ void primary_jitter(Rng& s, T& ox, T& oy) {
-    ox = Real<T>::uniform(s) - (T)0.5;
-    oy = Real<T>::uniform(s) - (T)0.5;
-}
-template <class T>
-__device__ __forceinline__ void primary_finish(const RenderParams<T>& p, int i, int j, T ox, T oy, bool defocus, T px, T py, V3<T>& O, V3<T>& D, T& sky_uy) {
-    const auto& c = cam_of(p);
-    const T fi = (T)i + ox, fj = (T)j + oy;
-    const V3<T> ps = madd3(fj, V3<T>{c.dv.x, c.dv.y, c.dv.z}, madd3(fi, V3<T>{c.du.x, c.du.y, c.du.z}, V3<T>{c.pixel00.x, c.pixel00.y, c.pixel00.z}));
-    const V3<T> ctr = {c.center.x, c.center.y, c.center.z};
-    V3<T> org = ctr;
-    if (defocus) org = madd3(py, V3<T>{c.ddv.x, c.ddv.y, c.ddv.z}, madd3(px, V3<T>{c.ddu.x, c.ddu.y, c.ddu.z}, ctr));
-    O = org;
-    D = {ps.x - org.x, ps.y - org.y, ps.z - org.z};
-    const T dd = dot3(D, D);
-    T inv;
-    if (p.range_flags & 1) inv = inv_sqrt_accepted(dd);   // wave-uniform choice, same bits
-    else inv = (T)1 / Real<T>::sqrt(dd);
-    sky_uy = inv * D.y;
-}
-
 // One primary ray: camera.h:145-155 (+ :73-76, vec3.h:109-115).  Also returns the y
 // component of the PRIMARY ray's unit direction, all the sky term needs (camera.h:121).
 template <class T>

@@ -157,7 +157,7 @@ __device__ __forceinline__ void xw_apply_jump(const uint32_t* __restrict__ m, ui
 // <= XW_LOW_BITS products), and rng_init_kernel starts every pixel from its table entry and applies only the HIGH bits' matrices -- which
 // consecutive pixels share, so a wave executes a product only for the set bits of its common high part.  1920 x 1080: 4.5 products per wave on
 // average instead of 13.5 (the six lowest bits differ between the lanes of a wave, so every one of their matrices was applied by every wave):
-// 1.3 -> 0.45 ms.  GF(2) linear algebra: the same states bit for bit (tests/test_gpu_parity.py, rocRAND known answers).
+// 1.26 -> 0.61 ms (rtiow_stats.rng_init_ms, profiles/r04/bench_n1.json).  GF(2) linear algebra: the same states bit for bit (tests/test_gpu_parity.py, rocRAND known answers).
 constexpr int XW_LOW_BITS = 12;
 __global__ void __launch_bounds__(256)
 xw_low_table_kernel(uint32_t* __restrict__ table, const uint32_t* __restrict__ jump, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t s4) {

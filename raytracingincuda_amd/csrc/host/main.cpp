@@ -340,16 +340,23 @@ int main(int argc, char** argv) {
         destroy_rc = rtiow_destroy(h);
         t_destroy = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     });
-    const int wrc = nan_channels == 0 ? rtiow_host_write_ppm_levels(name, opt.width, opt.height, lev.get(), opt.binary_ppm ? 1 : 0)
-                  : (opt.binary_ppm ? rtiow_host_write_ppm_binary(name, precision, opt.width, opt.height, rgb.get())
-                                    : rtiow_host_write_ppm(name, precision, opt.width, opt.height, rgb.get()));
+    // the thread is joined on EVERY way out of the write (a joinable std::thread's destructor terminates the process):
+    // a writer that throws -- bad_alloc on its format buffers -- counts as a failed write
+    int wrc = -1;
+    try {
+        wrc = nan_channels == 0 ? rtiow_host_write_ppm_levels(name, opt.width, opt.height, lev.get(), opt.binary_ppm ? 1 : 0)
+            : (opt.binary_ppm ? rtiow_host_write_ppm_binary(name, precision, opt.width, opt.height, rgb.get())
+                              : rtiow_host_write_ppm(name, precision, opt.width, opt.height, rgb.get()));
+    } catch (...) { wrc = -1; }
     const double t_write = lap();
     releaser.join();
+    // both results are reported: a failed release is not hidden behind a failed write
+    if (destroy_rc != 0) std::fprintf(stderr, "HIP_SAFE_CALL: releasing the device failed (error %d)\n", destroy_rc);
     if (wrc != 0) {
         std::fprintf(stderr, "Error: Could not open file for writing: %s\n", name);
         return -1;
     }
-    if (destroy_rc != 0) { std::fprintf(stderr, "HIP_SAFE_CALL: releasing the device failed (error %d)\n", destroy_rc); return destroy_rc; }
+    if (destroy_rc != 0) return destroy_rc;
     (void)lap();
     const auto e2e_stop = std::chrono::steady_clock::now();                  // main.cu:394
     const double e2e_ms = std::chrono::duration<double, std::milli>(e2e_stop - e2e_start).count();

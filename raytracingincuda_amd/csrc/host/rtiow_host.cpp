@@ -5,7 +5,6 @@
 #include "rtiow_host.h"
 
 #include <fcntl.h>
-#include <sys/mman.h>
 #include <unistd.h>
 #include <sys/types.h>
 
@@ -354,7 +353,7 @@ int rtiow_host_write_ppm_levels(const char* path, int width, int height, const u
     const size_t npix = (size_t)width * height;
     char head[64];
     const int hn = std::snprintf(head, sizeof head, "%s\n%d %d\n255\n", binary ? "P6" : "P3", width, height);
-    const int fd = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);          // read access too: the text body is written through a mapping
+    const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);        // header and body go out through pwrite
     if (fd < 0) return RTIOW_E_STATE;
     auto write_all = [fd](const char* d, size_t n, off_t at) {
         while (n) {

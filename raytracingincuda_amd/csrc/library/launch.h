@@ -65,7 +65,6 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     // A scene whose tables do not fit the CU's LDS next to the drain scratch (several thousand
     // spheres) is read through the scalar cache instead of failing: same image, exact loop.
     size_t coop_scratch = persistent ? (size_t)((threads + 63) / 64) * COOP_SLOTS * sizeof(CoopSlot<T>) : 0;
-    if (RTIOW_POOLED && persistent && coop_scratch < sizeof(PoolArea<T>)) coop_scratch = sizeof(PoolArea<T>);   // the pooled loop's area lies where the drain's slots lie
     bool lds_source = h->scene_source != RTIOW_SCENE_SCALAR;
     int effective_source = h->scene_source;
     const bool screened = h->scene_source == RTIOW_SCENE_LDS || h->scene_source == RTIOW_SCENE_GRID;

@@ -93,10 +93,10 @@ int rtiow_debug_path_stats(unsigned long long* out, int cap_words, int reset) {
 // hipStreamDestroy tears down a hardware queue (~3 ms, most of what rtiow_destroy took inside the executables'
 // end-to-end time); the runtime releases the idle ones at process exit.
 namespace {
-std::mutex g_idle_streams_mu;
-std::vector<std::pair<int, hipStream_t>> g_idle_streams;
+static std::mutex g_idle_streams_mu;
+static std::vector<std::pair<int, hipStream_t>> g_idle_streams;
 
-hipError_t acquire_stream(int device, hipStream_t* out) {
+static hipError_t acquire_stream(int device, hipStream_t* out) {
     {
         std::lock_guard<std::mutex> lock(g_idle_streams_mu);
         for (size_t k = 0; k < g_idle_streams.size(); ++k)
@@ -109,7 +109,7 @@ hipError_t acquire_stream(int device, hipStream_t* out) {
     return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
 }
 
-void release_stream(int device, hipStream_t s) {
+static void release_stream(int device, hipStream_t s) {
     std::lock_guard<std::mutex> lock(g_idle_streams_mu);
     g_idle_streams.emplace_back(device, s);
 }
@@ -286,7 +286,7 @@ int rtiow_init_rng(rtiow_handle h, uint64_t seed) {
 namespace {
 // First half of rtiow_render: everything up to and including the stop event, nothing that blocks
 // the host (main.cu:334-339 without the synchronisation).
-int render_begin(rtiow_handle_s* h, int T, bool timed) {
+static int render_begin(rtiow_handle_s* h, int T, bool timed) {
     if (!h->have_camera || h->n == 0) return fail_arg(h, RTIOW_E_STATE, "rtiow_render before rtiow_set_scene/rtiow_set_camera");
     if (!h->rng_ready) return fail_arg(h, RTIOW_E_STATE, "rtiow_render before rtiow_init_rng");
     if (T < 0 || T > 32) return fail_arg(h, RTIOW_E_BADARG, "rtiow_render: threads_per_block_row must be 0..32");
@@ -315,7 +315,7 @@ int render_begin(rtiow_handle_s* h, int T, bool timed) {
 }
 
 // Second half: wait for the stop event and read the event times (main.cu:337, 340-341).
-int render_wait(rtiow_handle_s* h, float* kernel_ms) {
+static int render_wait(rtiow_handle_s* h, float* kernel_ms) {
     if (!h->render_pending) { if (kernel_ms) *kernel_ms = (float)h->stats.render_ms; return 0; }
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipEventSynchronize(h->ev1));

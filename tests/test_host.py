@@ -42,6 +42,14 @@ def test_c_abi_exports_every_declared_symbol(native):
     dsyms = subprocess.run(["nm", "-D", "--defined-only", paths["hip_debug"]], capture_output=True, text=True, check=True).stdout
     for s in hip_decl + dbg_decl:
         assert re.search(r"\bT %s\b" % s, dsyms), s
+    # ... and nothing but the ABI: the library is linked into someone else's main.cu (main.cu:335), so no helper function, global
+    # or libstdc++ instantiation may leak out of it (csrc/librtiow_hip.map); the host library's names are rtiow_host_* likewise
+    for table, decl in ((syms, hip_decl), (dsyms, hip_decl + dbg_decl)):
+        exported = [l.split()[-1] for l in table.splitlines() if l.strip()]
+        assert sorted(exported) == sorted(decl), sorted(set(exported) ^ set(decl))
+    hsyms = subprocess.run(["nm", "-D", "--defined-only", paths["host"]], capture_output=True, text=True, check=True).stdout
+    stray = [l.split()[-1] for l in hsyms.splitlines() if l.split()[1] in "TBD" and not l.split()[-1].startswith("rtiow_host_")]
+    assert not stray, stray
 
 
 def test_no_gpu_means_loud_failure_not_fallback(native):
