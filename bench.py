@@ -33,6 +33,11 @@ Prints ONE JSON line on rank 0.  Extra objects:
                 not executed work (the grid walk tests a few spheres per segment), so it may exceed the peak.
                 `traffic` = HBM bytes of the launch from the FETCH_SIZE / WRITE_SIZE passes (separate passes, gfx950
                 x2 fetch correction as an upper bound), against `algorithmic_hbm_bytes_per_launch`.
+                N > 1: every rank's main launch is rated the same way -- its own launch time, measured live on its device, against
+                the SQ_INSTS_VALU of ITS shard from the committed per-shard records (profiles/pmc_records.json, keys ..._r<k>of<N>x<strip>,
+                taken on one GPU by scripts/pmc_shard_records.py; a shard executes the same instructions on any device).  `frac` is
+                then the fraction of the rank whose main launch is the longest (the one that bounds the step), `frac_per_rank` lists
+                all; null for a rank without a record of the loaded build.
   cpu_baseline  the reference's serial tracer (oracle/_ref, built from the reference's own sources) or, if absent,
                 the oracle's serial port, timed on this host (1 thread) on a bounded sample of the same workload;
                 "config1" inside it is BASELINE.json configs[0] in full
@@ -59,14 +64,17 @@ HBM_PEAK_GBS = 8000.0
 # What the part gives a stream of plain (un-packed) independent FMAs, measured with bin/valu_peak (profiles/archive/r01_valu_peak.json): v_fma_f32 80.85 TFLOP/s
 # at 4 waves per SIMD, 84.65 at 8 (v_pk_fma_f32: 125-128); v_fma_f64 61.57 at 4 waves.  The render kernels run 5 (fp32) / 4 (fp64) waves per SIMD.
 PRACTICAL_FMA_TFLOPS = {32: 82.0, 64: 61.57}
-# Share of the fp64 main kernel's vector instructions that issue at the double-precision rate (v_*_f64: one wave64 instruction per 4 cycles; the rest --
-# generator steps, integer and fp32 grid walk, moves -- per 2), from the kernel's static ISA; tests/test_kernel_resources.py keeps it within +-0.04 of the compiler's.
+# fp64 kernels: double-precision add / mul / fma wave-instructions are charged 4 SIMD-32 cycles, double-precision transcendentals (v_rcp_f64, v_rsq_f64,
+# v_sqrt_f64) 8, everything else -- generator steps, integer and fp32 grid walk, moves -- 2.  Which instructions those are comes from EXECUTED counts
+# (the "f64" pass of scripts/pmc_passes.py: SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64).  Only when a record lacks that pass: the share of v_*_f64 in the
+# kernel's static ISA (tests/test_kernel_resources.py keeps it within +-0.04 of the compiler's), flagged "static" in the line.
 FP64_KERNEL_DP_SHARE = 0.69
+DP_CYCLES, DP_TRANS_CYCLES = 4.0, 8.0
 # Configurations rendered after the headline's timed region, from the same loaded library, so that the round's claims about them are on the
 # driver's clock too (N = 1 only): name -> (scene, W, H, spp, bounces, precision)
 EXTRA_CONFIGS = [("fp64_headline", (3, 1920, 1080, 100, 50, 64)), ("scene1_487_spheres_1080p", (1, 1920, 1080, 100, 50, 32)),
                  ("baseline_config2_scene1_320x192_10spp_25b", (1, 320, 192, 10, 25, 32))]
-PMC_RECORDS = os.path.join(ROOT, "profiles", "pmc_records.json")
+PMC_RECORDS = os.environ.get("RTIOW_PMC_RECORDS") or os.path.join(ROOT, "profiles", "pmc_records.json")    # the committed counter records (the override is for tests)
 
 
 def parse():
@@ -169,16 +177,20 @@ def under_a_profiler():
     return any(k.startswith("ROCPROFILER_") or k.startswith("ROCP_") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
 
 
+def live_passes(precision, traffic=True):
+    return ("sq",) + (("fetch", "write") if traffic else ()) + (("f64",) if precision == 64 else ())
+
+
 def pmc_live(args):
     """The rocprofv3 --pmc passes of this configuration, run NOW as child processes over the library this bench is
     about to load (must be called before this process initialises the GPU).  Returns (record | None, note)."""
     import pmc_passes
     try:
-        rec = pmc_passes.collect(pmc_config(args), reps=2, timeout=420)
+        rec = pmc_passes.collect(pmc_config(args), passes=live_passes(args.precision), reps=2, timeout=420)
     except Exception as e:                       # no rocprofv3, no permission, a failing pass: the bench line still prints
         return None, "live passes failed: %s" % str(e)[:300]
     return rec, "rocprofv3 --pmc child processes of this bench.py run (scripts/pmc_passes.py), %s" % ", ".join(
-        "%s %.1f s" % (p["cmd"].split("--pmc ")[1].split()[0], p["seconds"]) for p in rec["passes"])
+        "%s %.1f s" % (p.get("pass") or p["cmd"].split("--pmc ")[1].split()[0], p["seconds"]) for p in rec["passes"])
 
 
 def pmc_committed(args, build_id):
@@ -188,6 +200,24 @@ def pmc_committed(args, build_id):
     if rec is None:
         return None, "no record for %s taken on build %s... in %s" % (key, build_id[:12], os.path.relpath(PMC_RECORDS, ROOT))
     return rec, "committed record %s[%s], build id matches the loaded library" % (os.path.relpath(PMC_RECORDS, ROOT), key)
+
+
+def shard_records(args, world, build_id):
+    """N > 1: the committed counter record of every rank's shard (scripts/pmc_shard_records.py), or None where there is none for the loaded build."""
+    import pmc_passes
+    if args.pmc == "off":
+        return [None] * world, "--pmc off"
+    recs = []
+    for k in range(world):
+        key = pmc_passes.config_key(args.scene_id, args.width, args.height, args.samples, args.bounces, args.precision, args.schedule, args.scene_source,
+                                    shard=(k, world, args.strip_rows))
+        recs.append(pmc_passes.load_record(PMC_RECORDS, key, build_id))
+    have = sum(r is not None for r in recs)
+    note = ("per-shard records %s[..._r<k>of%dx%d] of the loaded build (SQ_INSTS_VALU of a shard, taken on one GPU: scripts/pmc_shard_records.py) for %d of %d ranks; "
+            "each rank's launch time is its own, measured in this run" % (os.path.relpath(PMC_RECORDS, ROOT), world, args.strip_rows, have, world))
+    if have == 0:
+        note = "no per-shard record of build %s... in %s (N > 1 uses committed records: scripts/pmc_shard_records.py)" % (build_id[:12], os.path.relpath(PMC_RECORDS, ROOT))
+    return recs, note
 
 
 def lone_ray_trip_us(rt, device_index, prec, scene, args):
@@ -204,12 +234,28 @@ def lone_ray_trip_us(rt, device_index, prec, scene, args):
     return (best * 1e3 / segs if segs else None), segs
 
 
-def issue_fraction(valu_insts, launch_ms, precision, cus=256, clock_mhz=2400):
+def issue_fraction(valu_insts, launch_ms, precision, cus=256, clock_mhz=2400, dp=None):
     """(frac, cycles_per_inst): share of the SIMD-32 issue cycles the launch's vector instructions take.  fp32: 2 cycles per wave64 instruction.
-    fp64: the kernel's double-precision instructions (FP64_KERNEL_DP_SHARE of them) take 4, the others 2.  The device's compute units and
-    nominal clock come from the library (rtiow_stats.num_cus / clock_mhz = hipDeviceProp_t), not from a constant."""
-    cpi = 2.0 if precision == 32 else 2.0 * (1.0 - FP64_KERNEL_DP_SHARE) + 4.0 * FP64_KERNEL_DP_SHARE
+    fp64: `dp` = (double-precision add/mul/fma, double-precision transcendental) wave-instructions that EXECUTED (pmc_passes.dp_instruction_counts)
+    are charged 4 and 8 cycles, the others 2; without those counts the static ISA share FP64_KERNEL_DP_SHARE stands in for them.
+    The device's compute units and nominal clock come from the library (rtiow_stats.num_cus / clock_mhz = hipDeviceProp_t), not from a constant."""
+    if precision == 32:
+        cpi = 2.0
+    elif dp is not None:
+        cpi = (2.0 * (valu_insts - dp[0] - dp[1]) + DP_CYCLES * dp[0] + DP_TRANS_CYCLES * dp[1]) / valu_insts
+    else:
+        cpi = 2.0 * (1.0 - FP64_KERNEL_DP_SHARE) + DP_CYCLES * FP64_KERNEL_DP_SHARE
     return cpi * valu_insts / (cus * 4 * clock_mhz * 1e6 * launch_ms * 1e-3), cpi
+
+
+def dp_counts(rec, valu_insts):
+    """The executed double-precision counts of a record, scaled to `valu_insts` (the f64 pass counts its own SQ_INSTS_VALU: runs differ by a few 1e-4)."""
+    import pmc_passes
+    main = rec["counters"].get("main", {})
+    dp = pmc_passes.dp_instruction_counts(main)
+    if dp is None or not main.get("SQ_INSTS_VALU"):
+        return None
+    return dp
 
 
 def device_of(st):
@@ -247,17 +293,19 @@ def run_extra_configs(rt, device_index, args, extra_pmc):
             key = pmc_passes.config_key(scene_id, W, H, S, B, prec, args.schedule, args.scene_source)
             rec = pmc_passes.load_record(PMC_RECORDS, key, rt.build_id())
             note = "committed record of this build" if rec else None
-        frac = lanes = None
+        frac = lanes = dp_basis = None
         if rec and rec.get("build_id") == rt.build_id():
             main = rec["counters"].get("main", {})
             if main.get("SQ_INSTS_VALU"):
-                frac = round(issue_fraction(main["SQ_INSTS_VALU"], float(np.mean(main_ms)), prec, **device_of(st))[0], 4)
+                frac = round(issue_fraction(main["SQ_INSTS_VALU"], float(np.mean(main_ms)), prec, dp=dp_counts(rec, main["SQ_INSTS_VALU"]) if prec == 64 else None, **device_of(st))[0], 4)
+                if prec == 64:
+                    dp_basis = "executed (SQ_INSTS_VALU_*_F64)" if dp_counts(rec, main["SQ_INSTS_VALU"]) else "static ISA share"
             d = pmc_passes.derive(main)
             lanes = round(d["active_lane_frac"], 4) if "active_lane_frac" in d else None
         out.append({"name": name, "workload": "scene %d (%d spheres), %dx%d, %d spp, %d bounces, fp%d" % (scene_id, st["num_spheres"], W, H, S, B, prec),
                     "steps": steps, "ms_per_step": round(ms, 4), "value": round(float(W) * H * S / (ms * 1e-3) / 1e6, 3), "unit": "Mrays/s",
                     "main_launch_ms": round(float(np.mean(main_ms)), 4), "prepass_ms": round(float(st["prepass_ms"]), 4),
-                    "frac": frac, "active_lane_frac": lanes, "counters_from": note})
+                    "frac": frac, "active_lane_frac": lanes, "counters_from": note, **({"dp_cycles_from": dp_basis} if prec == 64 else {})})
     return out
 
 
@@ -265,8 +313,29 @@ SOURCES = {"grid": "SCENE_GRID", "lds": "SCENE_LDS", "scalar": "SCENE_SCALAR", "
 SCHEDULES = {"sorted": "SCHED_SORTED", "persistent": "SCHED_PERSISTENT", "static": "SCHED_STATIC"}
 
 
-def roofline_object(args, st, segments_main_rank0, main_ms, pmc, pmc_note, world):
-    """The dominant kernel (rank 0's main launch) against the vector-issue peak; see the module docstring."""
+def rank_fractions(args, ranks, dev):
+    """N > 1: every rank's main launch against the issue peak of ITS device -- `ranks` = [{"pmc": record of that rank's shard (this build) or None,
+    "main_ms": mean HIP-event time of its main launch, measured on its own device}].  Returns (per-rank list, index of the rank whose main launch
+    is the longest = the one that bounds the step)."""
+    import pmc_passes
+    out = []
+    for k, rk in enumerate(ranks):
+        rec, mms = rk.get("pmc"), rk.get("main_ms")
+        entry = {"rank": k, "main_launch_ms": round(mms, 4) if mms else None, "frac": None, "valu_wave_insts": None, "active_lane_frac": None}
+        main = rec["counters"].get("main", {}) if rec else {}
+        if main.get("SQ_INSTS_VALU") and mms:
+            insts = main["SQ_INSTS_VALU"]
+            frac, _ = issue_fraction(insts, mms, args.precision, dp=dp_counts(rec, insts) if args.precision == 64 else None, **dev)
+            d = pmc_passes.derive(main)
+            entry.update({"frac": round(frac, 4), "valu_wave_insts": insts, "active_lane_frac": round(d["active_lane_frac"], 4) if "active_lane_frac" in d else None})
+        out.append(entry)
+    timed = [e for e in out if e["main_launch_ms"]]
+    slowest = max(timed, key=lambda e: e["main_launch_ms"])["rank"] if timed else 0
+    return out, slowest
+
+
+def roofline_object(args, st, segments_main_rank0, main_ms, pmc, pmc_note, world, ranks=None):
+    """The dominant kernel (the main launch: rank 0's at N = 1, the slowest rank's at N > 1) against the vector-issue peak; see the module docstring."""
     prec, S = args.precision, args.samples
     nspheres = st["num_spheres"]
     my_rays = float(st["primary_rays"])
@@ -282,44 +351,70 @@ def roofline_object(args, st, segments_main_rank0, main_ms, pmc, pmc_note, world
     state_bytes = ((48 if prec == 32 else 64) + 4) if st["phases"] == 2 else 24
     fb_bytes = my_pixels * (3 * (4 if prec == 32 else 8) + state_bytes)
     achieved = frac = traffic = fetch_b = write_b = None
-    issued = None
-    if pmc is not None and world == 1:
+    issued = saturation = per_rank = None
+    dp_basis = None
+    dev = device_of(st)
+    dominant_rank = 0
+    if world > 1 and ranks:
+        per_rank, dominant_rank = rank_fractions(args, ranks, dev)
+        pmc = ranks[dominant_rank].get("pmc")             # the record the headline fraction is computed from
+        mms_dom = ranks[dominant_rank].get("main_ms") or mms
+    else:
+        mms_dom = mms
+        if world > 1:
+            pmc = None
+    if pmc is not None:
         import pmc_passes
         main = pmc["counters"].get("main", {})
-        d = pmc_passes.derive(main, launch_ms=mms)
+        d = pmc_passes.derive(main, launch_ms=mms_dom)
         if d.get("valu_wave_insts_per_launch"):
             # frac = share of the SIMD-32 issue slots filled (2 cycles per wave64 instruction, 1024 SIMDs, 2.4 GHz); achieved = that share of
             # the peak, i.e. one FMA issue slot = 64 lanes x 2 flop (fp64 FMA slots are half as many per second: the fp64 peak above)
-            dev = device_of(st)
-            frac, cycles_per_inst = issue_fraction(d["valu_wave_insts_per_launch"], mms, prec, **dev)
+            dp = dp_counts(pmc, d["valu_wave_insts_per_launch"]) if prec == 64 else None
+            dp_basis = None if prec == 32 else ("executed" if dp is not None else "static")
+            frac, cycles_per_inst = issue_fraction(d["valu_wave_insts_per_launch"], mms_dom, prec, dp=dp, **dev)
             # the peaks are MI355X's (256 CUs at 2.4 GHz): on any other part the fraction still holds, the TFLOP/s figures are scaled with it
             peak = peak * dev["cus"] * dev["clock_mhz"] / (256.0 * 2400.0)
             achieved = frac * peak
             issued = {"valu_wave_insts_per_launch": d["valu_wave_insts_per_launch"],
                       "valu_issue_frac": round(d["valu_issue_frac"], 4),    # every instruction at 2 cycles (the fp32 figure; a lower bound in fp64)
                       "cycles_per_inst_charged": round(cycles_per_inst, 3),
+                      "dp_insts_per_launch": d.get("dp_insts_per_launch"), "dp_trans_insts_per_launch": d.get("dp_trans_insts_per_launch"),
+                      "dp_share_executed": round(d["dp_share_executed"], 4) if "dp_share_executed" in d else None,
                       "simd_cycles_per_valu_inst_profiled": round(d["simd_cycles_per_valu_inst"], 3) if "simd_cycles_per_valu_inst" in d else None,
                       "valu_issue_frac_at_profiled_clock": round(d["valu_issue_frac_at_profiled_clock"], 4) if "valu_issue_frac_at_profiled_clock" in d else None,
                       "active_lane_frac": round(d["active_lane_frac"], 4) if "active_lane_frac" in d else None,
                       "salu_insts_per_launch": main.get("SQ_INSTS_SALU"),
                       "wave_cycles_split": {k: main.get(k) for k in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA") if main.get(k)},   # quad-cycles of resident waves: waiting (s_waitcnt), waiting for an issue slot, issuing vector / scalar instructions
                       "prepass_valu_wave_insts": pmc["counters"].get("prepass", {}).get("SQ_INSTS_VALU")}
+            if main.get("SQ_ACTIVE_INST_VALU"):
+                # How busy the vector pipes are, from the counters alone (no peak, no clock): a resident wave is "issuing a vector instruction"
+                # for SQ_ACTIVE_INST_VALU quad-cycles; per instruction that is how long one occupies its SIMD's issue stage.
+                busy = 4.0 * main["SQ_ACTIVE_INST_VALU"] / d["valu_wave_insts_per_launch"]
+                saturation = {"simd_cycles_busy_per_valu_inst": round(busy, 3),
+                              "simd_valu_busy_share": round(4.0 * main["SQ_ACTIVE_INST_VALU"] / (d["launch_cycles_profiled"] * pmc_passes.N_SIMD), 4) if d.get("launch_cycles_profiled") else None,
+                              "what": "4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = SIMD cycles a vector instruction of this launch occupies its issue stage (a stream of independent "
+                                      "v_fma_f32 measures 3.9 at five waves per SIMD, v_pk_* 5.9, v_fma_f64 4.6: bin/valu_cost), and the same busy time as a share of all SIMD cycles "
+                                      "of the profiled launch (GRBM_GUI_ACTIVE; waves overlap in the stage, so it can pass 1): at ~1 the SIMDs have no issue cycles left -- fewer "
+                                      "wave-instructions or more lanes per instruction are the only levers"}
         t = pmc.get("traffic_main")
         if t:
             traffic, fetch_b, write_b = t["hbm_bytes"], t["fetch_bytes_raw"], t["write_bytes"]
     kernel = {"static": "render_kernel", "persistent": "render_persistent_kernel", "sorted": "render_solo_kernel" if st["solo_waves"] else "render_persistent_kernel"}[args.schedule]
-    return {"bound": "valu", "achieved": round(achieved, 3) if achieved is not None else None, "peak": peak, "unit": "TFLOP/s",
+    fp64_text = ""
+    if prec == 64:
+        fp64_text = ("; in this fp64 kernel the double-precision add / mul / fma instructions that executed (SQ_INSTS_VALU_*_F64, the run's own \"f64\" pass) are charged 4 and its "
+                     "double-precision transcendentals 8" if dp_basis != "static" else
+                     "; in this fp64 kernel %.0f %% of them are double-precision instructions charged 4 (static ISA share, tests/test_kernel_resources.py: no executed counts in the record)"
+                     % (100 * FP64_KERNEL_DP_SHARE))
+    out = {"bound": "valu", "achieved": round(achieved, 3) if achieved is not None else None, "peak": peak, "unit": "TFLOP/s",
             "frac": round(frac, 4) if frac is not None else None, "traffic": traffic,
             "achieved_is": "EXECUTED vector issue: frac = SIMD-32 issue cycles of the main launch's SQ_INSTS_VALU wave-instructions / (1024 SIMDs x 2.4 GHz x launch time), "
-                           "a wave64 instruction charged 2 cycles" + ("" if prec == 32 else "; in this fp64 kernel %.0f %% of them are double-precision instructions charged 4 "
-                           "(static ISA share, tests/test_kernel_resources.py): %.2f cycles per instruction" % (100 * FP64_KERNEL_DP_SHARE, 2 + 2 * FP64_KERNEL_DP_SHARE)) +
+                           "a wave64 instruction charged 2 cycles" + fp64_text +
                            "; achieved = frac x peak (the FMA slots of this precision: 64 lanes x 2 flop per 2 (fp32) / 4 (fp64) cycles per SIMD). null: no counters for THIS build",
-            "practical_peak": {"value": PRACTICAL_FMA_TFLOPS[prec], "unit": "TFLOP/s",
-                               "what": "measured ceiling of a stream of plain independent %s at %d waves per SIMD (bin/valu_peak, profiles/archive/r01_valu_peak.json): what the "
-                                       "part gives un-packed vector code; v_pk_fma_f32 reaches 125-128" % (("v_fma_f32", 5) if prec == 32 else ("v_fma_f64", 4)),
-                               "frac_of_practical": round(achieved / PRACTICAL_FMA_TFLOPS[prec], 4) if achieved is not None else None},
+            "issue_saturation": saturation,
             "counters_from": pmc_note, "build_id": pmc.get("build_id") if pmc else None, "issued": issued,
-            "device": device_of(st),    # what frac is rated against: 4 SIMDs per compute unit at the nominal clock, both from hipDeviceProp_t through the library
+            "device": dev,    # what frac is rated against: 4 SIMDs per compute unit at the nominal clock, both from hipDeviceProp_t through the library
             "algorithmic_TFLOPs": round(algorithmic, 3), "algorithmic_frac": round(algorithmic / peak, 4),
             "algorithmic_is": "the reference's own sphere loop served per second: 23 flop x every sphere x every segment + 120 per segment + 60 per ray "
                               "(SURVEY.md 8d); the grid walk finds the same hits testing a few spheres per segment, so this is comparable work, not executed work",
@@ -330,6 +425,15 @@ def roofline_object(args, st, segments_main_rank0, main_ms, pmc, pmc_note, world
             "samples_in_launch": int(S - st["prepass_samples"]),
             "algorithmic_hbm_bytes_per_launch": fb_bytes,
             "hbm_achieved_GBps": round((traffic if traffic else fb_bytes) / (mms * 1e-3) / 1e9, 3), "hbm_peak_GBps": HBM_PEAK_GBS}
+    if prec == 64:
+        out["dp_cycles_from"] = dp_basis
+    if per_rank is not None:
+        out["frac_per_rank"] = per_rank
+        out["frac_is_rank"] = dominant_rank        # the rank whose main launch is the longest; algorithmic_* and launch_ms_* stay rank 0's
+        fr = [e["frac"] for e in per_rank if e["frac"] is not None]
+        out["frac_max_over_ranks"] = max(fr) if fr else None
+        out["frac_mean_over_ranks"] = round(float(np.mean(fr)), 4) if fr else None
+    return out
 
 
 def emit(json_fd, args, ctx):
@@ -356,7 +460,7 @@ def emit(json_fd, args, ctx):
         "kernel_ms_mean": round(kms, 4), "kernel_ms_min": round(float(np.min(ctx["kernel_ms"])), 4),
         "kernel_ms_mean_max_over_ranks": round(ctx["kernel_mean_max"], 4),
         "segments_per_ray": round(ctx["segments_total"] / rays, 4),
-        "roofline": roofline_object(args, st, ctx["segments_main0"], ctx["main_ms"], ctx["pmc"], ctx["pmc_note"], world),
+        "roofline": roofline_object(args, st, ctx["segments_main0"], ctx["main_ms"], ctx["pmc"], ctx["pmc_note"], world, ctx.get("ranks")),
         "step": {"launches": "prepass (%d spp) + cost sort + main" % st["prepass_samples"] if st["phases"] == 2 else "main",
                  "kernel_ms_mean": round(kms, 4), "prepass_ms": round(float(st["prepass_ms"]), 4),
                  "scene_prepare_ms": round(float(st["scene_prepare_ms"]), 3),   # host: screening table + grid plan, once per scene, before the first render's start event
@@ -370,6 +474,7 @@ def emit(json_fd, args, ctx):
         "floor_ms": round(ctx["floor_ms"], 4), "floor_is": "prepass_ms + longest per-pixel chain of the main launch x the trip latency of a lone ray on an idle GPU (1-pixel probe), max over ranks: "
                                                             "what a rank reaches if its longest chain runs undisturbed from the first trip; shards run it at 1.6-2x that "
                                                             "latency, two heavy pixels per solo wave beside the loaded SIMDs (DESIGN.md sections 4.3, 5)",
+        "efficiency_vs_floor": round(ctx["floor_ms"] / ms_per_step, 4) if ctx["floor_ms"] and ms_per_step else None,   # floor_ms / ms_per_step: 1 = the step is as short as its longest chain allows
         "longest_chain_segments": ctx["chain_max"], "lone_ray_trip_us": round(trip_us, 4) if trip_us else None,
         "lone_ray_probe": "1x1 frame, 400 spp, %d segments" % ctx["trip_segments"],
         "kernel_ms_per_rank": ctx["kernel_ms_per_rank"], "gather_ms_per_rank": ctx["gather_ms_per_rank"],
@@ -414,7 +519,7 @@ def run_group(args, json_fd):
         g.gather()
     for m in members:
         m.synchronize()
-    kernel_ms, main_ms, gather_ms, per_rank = [], [], [], []
+    kernel_ms, main_ms, gather_ms, per_rank, main_per_rank = [], [], [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         kernel_ms.append(g.render(args.threads))         # every device's launches are enqueued, then every stop event awaited: max over devices
@@ -422,13 +527,17 @@ def run_group(args, json_fd):
         gs = g.stats()
         per_rank.append(gs["kernel_ms"])
         gather_ms.append(gs["gather_ms"])
-        main_ms.append(members[0].stats()["main_ms"])
+        main_per_rank.append([m.stats()["main_ms"] for m in members])
+        main_ms.append(main_per_rank[-1][0])
     for m in members:
         m.synchronize()
     elapsed = time.perf_counter() - t0
     gs = g.stats()
     sts = [m.stats() for m in members]
     floor = max(float(sts[k]["prepass_ms"]) + chains[k] * (trip_us or 0.0) * 1e-3 for k in range(N))
+    recs, pmc_note = shard_records(args, N, rt.build_id())
+    main_mean = np.mean(np.array(main_per_rank), axis=0)
+    ranks = [{"pmc": recs[k], "main_ms": float(main_mean[k])} for k in range(N)]
     ctx = {"world": N, "elapsed": elapsed, "kernel_ms": kernel_ms, "main_ms": main_ms, "stats0": sts[0], "segments0": segments[0],
            "segments_main0": segments_main0, "segments_total": float(sum(segments)), "kernel_mean_max": float(np.mean(kernel_ms)),
            "kernel_ms_per_rank": [round(float(x), 4) for x in np.mean(np.array(per_rank), axis=0)],
@@ -438,7 +547,7 @@ def run_group(args, json_fd):
            "floor_ms": floor, "chain_max": max(chains), "trip_us": trip_us, "trip_segments": trip_segments,
            "sharding": "interleaved %d-row strips over %d ranks, one exchange to rank 0 inside the step" % (args.strip_rows, N),
            "backend": "rtiow_group (in-library RCCL / peer copies)", "host": "one process, devices %s" % ",".join(str(d) for d in devices),
-           "pmc": None, "pmc_note": "counter passes run at N = 1 only"}
+           "pmc": None, "pmc_note": pmc_note, "ranks": ranks}
     emit(json_fd, args, ctx)
     g.close()
 
@@ -490,8 +599,10 @@ def run_ranks(args, json_fd, world, rank, local_rank, distributed, pmc, pmc_note
     chain_main = int(r.stats()["max_chain_main"])      # this rank's longest per-pixel chain in the main launch
     trip_us, trip_segments = (None, 0) if args.no_scaling_probe else lone_ray_trip_us(rt, device_index, prec, scene, args)
 
+    rank_recs = None
     if world > 1:
-        pmc, pmc_note = None, "counter passes run at N = 1 only"
+        pmc = None
+        rank_recs, pmc_note = shard_records(args, world, rt.build_id())     # every rank reads the (small) committed file; rank 0 uses them
     elif args.pmc == "off":
         pmc, pmc_note = None, "--pmc off"
     elif pmc is None and args.pmc in ("auto", "committed"):      # no live passes (asked not to, or they failed): the committed record, if it is of THIS build
@@ -536,7 +647,8 @@ def run_ranks(args, json_fd, world, rank, local_rank, distributed, pmc, pmc_note
     st_local = r.stats()
     floor_local = float(st_local["prepass_ms"]) + chain_main * (trip_us or 0.0) * 1e-3
     if distributed:
-        t = torch.tensor([elapsed, float(np.mean(kernel_ms)), float(segments), gather_ms or 0.0, floor_local, float(chain_main)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, float(np.mean(kernel_ms)), float(segments), gather_ms or 0.0, floor_local, float(chain_main), float(np.mean(main_ms)) if main_ms else 0.0],
+                         dtype=torch.float64, device="cuda")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         per_rank = [torch.zeros_like(t) for _ in range(world)]
@@ -545,7 +657,9 @@ def run_ranks(args, json_fd, world, rank, local_rank, distributed, pmc, pmc_note
         gather_ms_max, floor_ms, chain_max = float(tmax[3]), float(tmax[4]), int(tmax[5])
         kernel_ms_per_rank = [round(float(x[1]), 4) for x in per_rank]
         gather_ms_per_rank = [round(float(x[3]), 4) for x in per_rank]
+        main_ms_per_rank = [float(x[6]) for x in per_rank]
     else:
+        main_ms_per_rank = None
         kernel_mean_max, segments_total = float(np.mean(kernel_ms)), float(segments)
         gather_ms_max, floor_ms, chain_max = None, floor_local, chain_main
         kernel_ms_per_rank, gather_ms_per_rank = [round(float(np.mean(kernel_ms)), 4)], None
@@ -562,7 +676,8 @@ def run_ranks(args, json_fd, world, rank, local_rank, distributed, pmc, pmc_note
                "sharding": "interleaved %d-row strips, gather to rank 0 inside the step" % args.strip_rows if distributed else "none",
                "backend": backend if distributed else None,
                "host": "one process per GPU (torch.distributed.run)" if distributed else "one process, device %d" % device_index,
-               "pmc": pmc, "pmc_note": pmc_note}
+               "pmc": pmc, "pmc_note": pmc_note,
+               "ranks": [{"pmc": rank_recs[k], "main_ms": main_ms_per_rank[k]} for k in range(world)] if rank_recs is not None and main_ms_per_rank else None}
         emit(json_fd, args, ctx)
     r.close()
     if distributed:
@@ -602,7 +717,7 @@ def main():
                 for name, (scene_id, W, H, S, B, prec) in EXTRA_CONFIGS:
                     cfg = dict(pmc_config(args), scene_id=scene_id, width=W, height=H, samples=S, bounces=B, precision=prec, threads=0)
                     try:
-                        extra_pmc[name] = pmc_passes.collect(cfg, passes=("sq",), reps=2, timeout=240)
+                        extra_pmc[name] = pmc_passes.collect(cfg, passes=live_passes(prec, traffic=False), reps=2, timeout=240)
                     except Exception:
                         pass
     run_ranks(args, json_fd, world, rank, local_rank, distributed, pmc, pmc_note, extra_pmc)

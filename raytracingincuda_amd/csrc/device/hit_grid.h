@@ -68,19 +68,44 @@ __device__ __forceinline__ void load_sphere(const double* aos, int i, double& cx
 }
 
 // The (up to) four spheres of one cell, hittable.h:42-57 each, for this lane's own ray.
+// Cells fill from slot 0 and pad with the never-hit entry (index n, `pad2` = n in both halves of a word): 35 % of the headline
+// scene's occupied cells hold one sphere, 43 % two, 18 % three, 5 % four (29 / 43 / 24 / 4 % on the 487-sphere scene).  Slots 2-3 are
+// therefore tested behind ONE wave-level branch: only when some lane of this step holds a third sphere -- 24 operations and
+// two gathers less for the late steps of a walk, which a handful of lanes run (RTIOW_CELL_PAIRS, default on; 0 = every slot always).
+#ifndef RTIOW_CELL_PAIRS
+#define RTIOW_CELL_PAIRS 2
+#endif
 template <class T>
-__device__ __forceinline__ void cell_tests(const T* aos, unsigned rec_lo, unsigned rec_hi, V3<T> O, V3<T> D, T a, T& closest, int& hit, FastDiv<T> fd) {
+__device__ __forceinline__ void cell_tests(const T* aos, unsigned rec_lo, unsigned rec_hi, unsigned pad2, V3<T> O, V3<T> D, T a, T& closest, int& hit, FastDiv<T> fd) {
     const int id[4] = {(int)(rec_lo & 0xffffu), (int)(rec_lo >> 16), (int)(rec_hi & 0xffffu), (int)(rec_hi >> 16)};
     T h[4], disc[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    auto slot = [&](int k) __attribute__((always_inline)) {
         T cx, cy, cz, r2;
         load_sphere(aos, id[k], cx, cy, cz, r2);
         const T ocx = cx - O.x, ocy = cy - O.y, ocz = cz - O.z;                         // :42
         h[k] = RT_FMA(D.z, ocz, RT_FMA(D.y, ocy, D.x * ocx));                            // :44
         const T c = RT_FMA(ocz, ocz, RT_FMA(ocy, ocy, ocx * ocx)) - r2;                  // :45
         disc[k] = RT_FMA(h[k], h[k], -(a * c));                                          // :47
+    };
+    if (RTIOW_CELL_PAIRS == 2) {
+        // pair after pair, each with its own candidate branch: two discriminants live at a time instead of four
+        auto pair = [&](int k) __attribute__((always_inline)) {
+            slot(k); slot(k + 1);
+            if (Real<T>::fmax(disc[k], disc[k + 1]) >= (T)0) {                              // :48 for either of the two
+                PATH_STAT(PS_EXACT_BLOCK);
+                if (disc[k] >= (T)0) finish_sphere_test<T, true>(id[k], h[k], disc[k], a, closest, hit, fd);
+                if (disc[k + 1] >= (T)0) finish_sphere_test<T, true>(id[k + 1], h[k + 1], disc[k + 1], a, closest, hit, fd);
+            }
+        };
+        pair(0);
+        if (__builtin_amdgcn_ballot_w64(rec_hi != pad2) != 0) { PATH_STAT(PS_CELL_PAIR2); pair(2); }
+        return;
     }
+    slot(0); slot(1);
+    if (RTIOW_CELL_PAIRS) {
+        h[2] = h[3] = (T)0; disc[2] = disc[3] = (T)-1;                                    // what a pad entry amounts to: never a candidate
+        if (__builtin_amdgcn_ballot_w64(rec_hi != pad2) != 0) { PATH_STAT(PS_CELL_PAIR2); slot(2); slot(3); }
+    } else { slot(2); slot(3); }
     const T m = Real<T>::fmax(Real<T>::fmax(disc[0], disc[1]), Real<T>::fmax(disc[2], disc[3]));
     if (m >= (T)0) {                                                                    // :48 for any of the four
         PATH_STAT(PS_EXACT_BLOCK);
@@ -186,6 +211,7 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
         if (__builtin_amdgcn_ballot_w64(walking) == 0) { REGION_END(walk, RG_GRID_WALK); return; }
         const T* aos = sizeof(T) == 4 ? reinterpret_cast<const T*>(smem_raw + g.aos_offset) : lds_exact;
         const uint2* cells = reinterpret_cast<const uint2*>(smem_raw + g.cells_offset);
+        const unsigned pad2 = (unsigned)p.n * 0x10001u;     // a cell record's upper word when slots 2 and 3 are pads
         const float px = __builtin_fmaf(t0, dx, ox), pz = __builtin_fmaf(t0, dz, oz);
         int cx = (int)__builtin_floorf(px * g.inv_cell), cz = (int)__builtin_floorf(pz * g.inv_cell);
         cx = cx < 0 ? 0 : (cx >= g.nx ? g.nx - 1 : cx);
@@ -206,7 +232,7 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
                 path_stat(step_no == 1 ? PS_STEP_1 : step_no == 2 ? PS_STEP_2 : step_no == 3 ? PS_STEP_3 : step_no == 4 ? PS_STEP_4 : step_no <= 8 ? PS_STEP_5_8 : PS_STEP_9_UP);
 #endif
                 const uint2 rec = cells[cz * g.nx + cx];
-                if (rec.x != 0xffffffffu) cell_tests<T>(aos, rec.x, rec.y, O, D, a, closest, hit, fdc);
+                if (rec.x != 0xffffffffu) cell_tests<T>(aos, rec.x, rec.y, pad2, O, D, a, closest, hit, fdc);
                 // the parameter at which the ray leaves this cell, per axis
                 const float bx = (float)(cx + (sx > 0 ? 1 : 0)) * g.cell, bz = (float)(cz + (sz > 0 ? 1 : 0)) * g.cell;
                 const float tx = step_x ? (bx - ox) * inv_dx : __builtin_huge_valf();

@@ -58,7 +58,7 @@ __device__ __forceinline__ void rt_opaque(Rng& r) { asm volatile("" : "+v"(r.v0)
 #ifdef RTIOW_PATH_STATS
 enum { PS_ITERATION = 0, PS_RUV_CALL, PS_RUV_ROUND, PS_DISK_ROUND, PS_GEN_PRIMARY, PS_SHADE_HIT, PS_SKY, PS_DIELECTRIC, PS_METAL,
        PS_EXACT_BLOCK, PS_FINISH_CALL, PS_IEEE_BLOCK, PS_SECOND_DIV, PS_SCHLICK_DRAW, PS_REFILL, PS_FINISH_PIXEL, PS_GRID_STEP,
-       PS_STEP_1, PS_STEP_2, PS_STEP_3, PS_STEP_4, PS_STEP_5_8, PS_STEP_9_UP, PS_WALK, PS_COUNT };
+       PS_STEP_1, PS_STEP_2, PS_STEP_3, PS_STEP_4, PS_STEP_5_8, PS_STEP_9_UP, PS_WALK, PS_CELL_PAIR2, PS_COUNT };
 __device__ unsigned long long g_path_stats[2 * PS_COUNT];
 __device__ __forceinline__ void path_stat(int region) {
     const unsigned long long act = __builtin_amdgcn_ballot_w64(true);

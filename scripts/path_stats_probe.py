@@ -13,7 +13,7 @@ scene = int(a[0]) if a else 3
 W, H, S, B = (int(x) for x in a[1:5]) if len(a) >= 5 else (1920, 1080, 100, 50)
 names = ["iteration", "ruv_call", "ruv_round", "disk_round", "gen_primary", "shade_hit", "sky", "dielectric", "metal",
          "exact_block", "finish_call", "ieee_block", "second_div", "schlick_draw", "refill", "finish_pixel", "grid_step",
-         "walk_step_1", "walk_step_2", "walk_step_3", "walk_step_4", "walk_step_5_8", "walk_step_9_up", "walk_entered"]
+         "walk_step_1", "walk_step_2", "walk_step_3", "walk_step_4", "walk_step_5_8", "walk_step_9_up", "walk_entered", "cell_second_pair"]
 r = rt.Renderer(0, 32); r.set_camera(rt.camera(32, W, H, S, B)); r.set_scene(rt.build_scene(scene, 32))
 sched = int(os.environ.get("RTIOW_PROBE_SCHED", "2"))
 r.init_rng(1227); r.set_schedule(sched, 0)

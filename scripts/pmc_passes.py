@@ -9,6 +9,12 @@ traffic is evidence that the path is nowhere near the memory roof.  Both come fr
                 SQ_WAIT_INST_ANY SQ_WAIT_ANY (the 8 SQ slots of gfx950) + GRBM_GUI_ACTIVE (its own block)
   pass "fetch"  FETCH_SIZE      } separate passes, as MI355X_MICROARCH.md (HBM, rocprofv3 PMC slots) prescribes:
   pass "write"  WRITE_SIZE      } the two do not fit the TCC's 4 slots together
+  pass "f64"    SQ_INSTS_VALU + SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 (fp64 kernels): the double-precision instructions that EXECUTED,
+                which bench.py charges 4 issue cycles (transcendentals 8) instead of 2
+
+A shard of a multi-GPU frame is a configuration of its own: cfg["shard"] = "rank,nranks,strip_rows" renders only that rank's row strips
+(one_render.py --shard) and the record's key ends in _r<rank>of<nranks>x<strip_rows>.  SQ_INSTS_VALU of a shard does not depend on which
+device renders it, so `bench.py --gpus N` rates every rank's main launch against records taken on ONE GPU (scripts/pmc_shard_records.py).
 
 Each pass profiles `python3 scripts/one_render.py <config>` (the program itself after `--`, nothing that re-execs).
 The record carries `build_id` = rtiow_build_id() of the library that rendered (SHA-256 of its sources and flags):
@@ -37,17 +43,24 @@ PASSES = {
            "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"],
     "fetch": ["FETCH_SIZE"],
     "write": ["WRITE_SIZE"],
+    "f64": ["SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"],
 }
+F64_COUNTERS = ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")
 SCHEDULES = {"static": 0, "persistent": 1, "sorted": 2}
 SOURCES = {"lds": 0, "scalar": 1, "lds_exact": 2, "grid": 3}
 N_SIMD = 256 * 4                      # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
 NOMINAL_GHZ = 2.4
 
 
-def config_key(scene_id, width, height, samples, bounces, precision, schedule="sorted", scene_source="grid"):
+def config_key(scene_id, width, height, samples, bounces, precision, schedule="sorted", scene_source="grid", shard=None):
+    """`shard` = (rank, nranks, strip_rows) or "rank,nranks,strip_rows" for one rank's row strips of the frame."""
     key = "s%d_%dx%d_%dspp_%db_f%d" % (scene_id, width, height, samples, bounces, precision)
     if (schedule, scene_source) != ("sorted", "grid"):
         key += "_%s_%s" % (schedule, scene_source)
+    if shard:
+        rank, nranks, strip = (int(x) for x in (shard.split(",") if isinstance(shard, str) else shard))
+        if nranks > 1:
+            key += "_r%dof%dx%d" % (rank, nranks, strip)
     return key
 
 
@@ -88,7 +101,8 @@ def parse_counter_tree(directory):
 def one_render_args(cfg, reps):
     return ["--scene", str(cfg["scene_id"]), "--w", str(cfg["width"]), "--h", str(cfg["height"]), "--s", str(cfg["samples"]),
             "--b", str(cfg["bounces"]), "--prec", str(cfg["precision"]), "--sched", str(SCHEDULES[cfg.get("schedule", "sorted")]),
-            "--source", str(SOURCES[cfg.get("scene_source", "grid")]), "--threads", str(cfg.get("threads", 0)), "--reps", str(reps), "--build-id"]
+            "--source", str(SOURCES[cfg.get("scene_source", "grid")]), "--threads", str(cfg.get("threads", 0)), "--reps", str(reps), "--build-id"] + (
+                ["--shard", str(cfg["shard"])] if cfg.get("shard") else [])
 
 
 def run_pass(cfg, counters, reps, timeout, keep_dir=None, log=None):
@@ -138,17 +152,30 @@ def derive(main, launch_ms=None):
             d["valu_issue_frac_at_profiled_clock"] = 2.0 * insts / (cycles * N_SIMD)
         if launch_ms:
             d["valu_issue_frac"] = 2.0 * insts / (N_SIMD * NOMINAL_GHZ * 1e9 * launch_ms * 1e-3)
+    dp = dp_instruction_counts(main)
+    if dp is not None:
+        d["dp_insts_per_launch"], d["dp_trans_insts_per_launch"] = dp
+        if insts:
+            d["dp_share_executed"] = (dp[0] + dp[1]) / insts
     return d
+
+
+def dp_instruction_counts(main):
+    """(add + mul + fma, transcendental) double-precision wave-instructions of a launch from the "f64" pass, or None without it."""
+    if not all(k in main for k in F64_COUNTERS):
+        return None
+    return (main["SQ_INSTS_VALU_ADD_F64"] + main["SQ_INSTS_VALU_MUL_F64"] + main["SQ_INSTS_VALU_FMA_F64"], main["SQ_INSTS_VALU_TRANS_F64"])
 
 
 def collect(cfg, passes=("sq", "fetch", "write"), reps=2, timeout=420, keep_root=None):
     """Run the passes; returns the record (see module docstring).  Raises on the first failing pass."""
     rec = {"config": dict(cfg), "key": config_key(cfg["scene_id"], cfg["width"], cfg["height"], cfg["samples"], cfg["bounces"], cfg["precision"],
-                                                  cfg.get("schedule", "sorted"), cfg.get("scene_source", "grid")),
+                                                  cfg.get("schedule", "sorted"), cfg.get("scene_source", "grid"), cfg.get("shard")),
            "counters": {}, "dispatches": {}, "passes": [], "collected_unix": int(time.time())}
     for name in passes:
         keep = os.path.join(keep_root, name) if keep_root else None
         means, counts, build_id, ms = run_pass(cfg, PASSES[name], reps, timeout, keep, rec["passes"])
+        rec["passes"][-1]["pass"] = name
         if not means.get("main"):
             raise RuntimeError("pass %s: no counters for the main launch" % name)
         if rec.get("build_id") not in (None, build_id):
@@ -190,8 +217,11 @@ def main():
     ap.add_argument("--schedule", default="sorted"); ap.add_argument("--scene_source", default="grid"); ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--passes", default="sq,fetch,write"); ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--keep", default=None, help="keep the raw rocprofv3 trees under this directory")
+    ap.add_argument("--shard", default="", help="rank,nranks,strip_rows: only that rank's row strips of the frame")
     a = ap.parse_args()
     cfg = {k: getattr(a, k) for k in ("scene_id", "width", "height", "samples", "bounces", "precision", "schedule", "scene_source", "threads")}
+    if a.shard:
+        cfg["shard"] = a.shard
     rec = collect(cfg, tuple(a.passes.split(",")), a.reps, keep_root=a.keep)
     data = json.load(open(a.out)) if os.path.exists(a.out) else {}
     data[rec["key"]] = rec

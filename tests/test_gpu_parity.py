@@ -907,7 +907,7 @@ def test_bench_prints_one_contract_line(rt):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert rf["unit"] == "TFLOP/s" and 0 < rf["launch_ms_mean"] <= d["kernel_ms_mean"] and rf["device"]["cus"] > 0 and rf["device"]["clock_mhz"] > 0
-    assert rf["practical_peak"]["value"] > 0 and rf["algorithmic_frac"] > 0 and d["step"]["scene_prepare_ms"] > 0
+    assert "practical_peak" not in rf and rf["algorithmic_frac"] > 0 and d["step"]["scene_prepare_ms"] > 0
     # frac is EXECUTED work: the vector-issue fraction from rocprofv3 --pmc passes this very run made over the loaded build.  bench.py is built to
     # degrade to null where the profiler cannot run (no permission, counter slots busy): the contract line must survive that (the live leg has its
     # own test below, which skips there)
@@ -915,13 +915,15 @@ def test_bench_prints_one_contract_line(rt):
         assert "live passes failed" in rf["counters_from"] or "no record" in rf["counters_from"], rf["counters_from"]
     else:
         assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1
-        assert rf["build_id"] == rt.build_id()
+        assert rf["build_id"] == rt.build_id() and rf["issue_saturation"]["simd_cycles_busy_per_valu_inst"] > 2.0
     # the other configurations of the round's claims ride along, rendered by the same library after the timed region
     ex = {e["name"]: e for e in d["extra_configs"]}
     assert set(ex) == {"fp64_headline", "scene1_487_spheres_1080p", "baseline_config2_scene1_320x192_10spp_25b"}
     for e in ex.values():
         assert e["ms_per_step"] > 0 and e["value"] > 0 and e["unit"] == "Mrays/s" and e["main_launch_ms"] <= e["ms_per_step"]
         assert e["frac"] is None or 0 < e["frac"] < 1.2
+    if ex["fp64_headline"]["frac"] is not None:       # the fp64 figure charges what EXECUTED at the double-precision rate (this run's own "f64" pass)
+        assert ex["fp64_headline"]["dp_cycles_from"].startswith("executed")
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and cb["sample"]
 
