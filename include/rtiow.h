@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RTIOW_ABI_VERSION 5
+#define RTIOW_ABI_VERSION 6
 
 #define RTIOW_E_BADARG   (-1)
 #define RTIOW_E_STATE    (-2)   /* call order violated (e.g. render before set_scene) */
@@ -131,6 +131,12 @@ typedef struct {
     double   place_ms;
     int32_t  clock_mhz;          /* its nominal shader clock (hipDeviceProp_t::clockRate): what an issue-slot figure is rated against */
     int32_t  reserved0;
+    /* ABI 6.  EFFECTIVE shader clock of the last timed render's launches (persistent schedules; 0: none taken): one wave of each launch --
+     * the first dispatched, resident until the hand-out runs dry -- stamps s_memtime and s_memrealtime when it starts and ends, the clock is
+     * d(s_memtime) / d(s_memrealtime) x 100 MHz over that wave's life.  A cold process whose render takes 16 ms instead of 11.6 shows here
+     * whether the chip was still ramping its clock (profiles/r05/cold_process_study.md). */
+    double   main_clock_mhz, prepass_clock_mhz;
+    double   main_wave0_ms;      /* that wave's life in the main launch (s_memrealtime), for reading main_clock_mhz against main_ms */
 } rtiow_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------

@@ -26,7 +26,7 @@ SCENE_LDS, SCENE_SCALAR, SCENE_LDS_EXACT, SCENE_GRID = 0, 1, 2, 3
 SCHED_STATIC, SCHED_PERSISTENT, SCHED_SORTED = 0, 1, 2
 GATHER_AUTO, GATHER_RCCL, GATHER_PEER, GATHER_HOST = 0, 1, 2, 3
 GROUP_MAX_STATS = 16
-ABI_VERSION = 5          # include/rtiow.h RTIOW_ABI_VERSION
+ABI_VERSION = 6          # include/rtiow.h RTIOW_ABI_VERSION
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIBDIR = os.path.join(_PKG, "lib")
@@ -72,7 +72,8 @@ class Stats(ctypes.Structure):
                 ("grid_direct", ctypes.c_int32), ("grid_cell", ctypes.c_double),
                 ("solo_waves", ctypes.c_int32), ("solo_lanes", ctypes.c_int32), ("scene_prepare_ms", ctypes.c_double),
                 ("staged_stores", ctypes.c_int32), ("num_cus", ctypes.c_int32), ("place_ms", ctypes.c_double),
-                ("clock_mhz", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+                ("clock_mhz", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+                ("main_clock_mhz", ctypes.c_double), ("prepass_clock_mhz", ctypes.c_double), ("main_wave0_ms", ctypes.c_double)]
 
 
 class GroupStats(ctypes.Structure):

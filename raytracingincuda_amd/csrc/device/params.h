@@ -68,6 +68,10 @@ template <class T> struct ColdParams {
     int solo_waves, solo_lanes;
     unsigned long long* timeline;     // COUNT variant, optional: per wave {t_start, t_exhausted, t_end, iters_normal, iters_coop, pixels, 0, 0}
     uint32_t* pixel_times;            // COUNT variant, optional (rtiow_debug_pixel_times): per local pixel {taken, finished (100 MHz ticks, low 32 bits), segments in this launch, wave}
+    // Effective shader clock of the launch (rtiow_stats.main_clock_mhz / prepass_clock_mhz): wave 0 of workgroup 0 -- dispatched first, and resident
+    // until the hand-out runs dry -- stores {s_memtime, s_memrealtime} when it starts and when it ends; clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
+    // (MI355X_MICROARCH.md, DVFS).  Pinned host memory, written by one lane twice per launch; nullptr: no stamps.
+    unsigned long long* clock_stamps;
 };
 
 // The camera (camera.h:10-30 as camera::initialize leaves it): 19 scalars that only gen_primary reads, once per

@@ -95,6 +95,15 @@ __device__ __forceinline__ bool tile_slot_pixel(const COLD& c, int slot, int& i,
     return i < c.W && jl < c.local_rows;
 }
 
+// {s_memtime, s_memrealtime} of wave 0 of workgroup 0 into ColdParams::clock_stamps[slot, slot + 1] (slot 0: the wave starts, 2: it ends).
+template <class T>
+__device__ __forceinline__ void clock_stamp(const RenderParams<T>& p, int slot) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long* s = cold_of(p).clock_stamps;
+        if (s) { s[slot] = __builtin_amdgcn_s_memtime(); s[slot + 1] = __builtin_amdgcn_s_memrealtime(); }
+    }
+}
+
 template <class T, int SRC, bool COUNT, bool SOLO = false, bool BOUND_F32 = false>
 __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
     const T* lds_geom = stage_scene<T, SRC>(p);
@@ -103,6 +112,7 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
     const T* lds_shade = reinterpret_cast<const T*>(smem_raw + p.shade_offset);
     CoopSlot<T>* coop_slots = reinterpret_cast<CoopSlot<T>*>(smem_raw + p.coop_offset) + (threadIdx.x >> 6) * COOP_SLOTS;
     const int S = p.s_end;                       // this launch renders samples [cold.s_begin, p.s_end)
+    clock_stamp(p, 0);                           // ColdParams::clock_stamps: one lane of the launch, here and behind the loop
 
     PathState<T> st;
     st.acc = {0, 0, 0};
@@ -298,6 +308,7 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
         REGION_END(acc, RG_ACCUMULATE);
         REGION_END(total, RG_LOOP_TOTAL);
     }
+    clock_stamp(p, 2);
     if (COUNT) {
         const auto& c = cold_of(p);
         atomicAdd(c.seg_counter, (unsigned long long)nseg);

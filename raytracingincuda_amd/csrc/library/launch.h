@@ -85,6 +85,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
     p.screen_offset = (int)lds;
     if (p.use_screen) lds += sizeof(float) * 4 * (size_t)h->n_padded;
     p.cold.timeline = nullptr;                                    // set below, once the grid is known
+    p.cold.clock_stamps = (!seg_counter && h->schedule != RTIOW_SCHED_STATIC && h->clock_stamps_dev) ? h->clock_stamps_dev + 4 : nullptr;   // the main (or only) launch; timed renders only
     p.cold.pixel_times = seg_counter ? h->pixel_times : nullptr;
     // shade records ride along in LDS while a workgroup's share stays within 1/5 of the CU's LDS
     const size_t coop_bytes = coop_scratch;
@@ -240,6 +241,7 @@ int launch_render(rtiow_handle_s* h, const CAM& cam, int bx, int by, int wave_ti
             RenderParams<T> pa = p;
             pa.s_end = SA; pa.cold.mid_out = h->mid; pa.cold.cost_out = h->cost;
             pa.cold.seg_counter = seg_counter;
+            if (pa.cold.clock_stamps) pa.cold.clock_stamps = h->clock_stamps_dev;          // the prepass's four words
             RenderFn<T> kp = bounded_f32 ? pick_bounded_kernel<T>(true, lds_source, seg_counter != nullptr) : pick_prepass_kernel<T>(lds_source, seg_counter != nullptr);
             if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kp, grid, block, lds, h->stream, pa);

@@ -37,6 +37,7 @@
 #include <new>
 #include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rtiow.h"
@@ -74,6 +75,8 @@ struct RcclApi {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;                    // optional (null in a library without them): the completion phase of the exchange
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;    // then watches the streams alone
     bool load(std::string& why) {
         if (lib) return true;
         const char* names[] = {getenv("RTIOW_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -88,6 +91,8 @@ struct RcclApi {
         RT_SYM(GroupStart, "ncclGroupStart") RT_SYM(GroupEnd, "ncclGroupEnd") RT_SYM(GetErrorString, "ncclGetErrorString")
         RT_SYM(GetVersion, "ncclGetVersion")
 #undef RT_SYM
+        CommAbort = (decltype(CommAbort))dlsym(lib, "ncclCommAbort");
+        CommGetAsyncError = (decltype(CommGetAsyncError))dlsym(lib, "ncclCommGetAsyncError");
         return true;
     }
 };
@@ -113,6 +118,12 @@ struct GatherBackend {
     int (*stream_sync)(void* self, hipStream_t s);
     int (*copy_via_host)(void* self, void* dst, int dst_dev, hipStream_t dst_stream, const void* src, int src_dev, size_t bytes);   // blocking D2H into a bounce buffer, H2D on dst_stream, awaited
     int (*drain)(void* self, int ndev, const int* dev);      // after a failing transport: every device idle, sticky errors cleared (never fails the chain)
+    // COMPLETION of the exchange: ncclSend / ncclRecv / ncclGroupEnd and hipMemcpyPeerAsync mostly fail or stall AFTER they were
+    // enqueued.  await = wait until everything enqueued on `s` is done, watching the communicator's asynchronous error state while waiting
+    // (comm null: peer copies) and giving up after a deadline; 0, or the error with *where naming its source.  abort_comms = ncclCommAbort
+    // on every communicator (a transport that failed is never used again, and its kernels must be gone before the devices are drained).
+    int (*await)(void* self, hipStream_t s, void* comm, const char** where);
+    int (*abort_comms)(void* self);
 };
 
 struct GatherInputs {
@@ -156,6 +167,14 @@ int run_gather_schedule(const GatherInputs& in, const GatherBackend& be, const c
         const int r2 = be.group_end(be.self);      // always closed, also after a failing call inside the group
         if (r == 0 && r2 != 0) { r = r2; failed = "ncclGroupEnd"; }
         if (r != 0) { where = failed; return r; }
+        // completion: every sender's stream, then stream 0 (the receives), each with its communicator's asynchronous error state
+        for (int k = in.n - 1; k >= 0; --k) {
+            if ((size_t)in.rows[k] * in.W * 3 == 0 && k != 0) continue;
+            GB(be.set_device(be.self, in.dev[k]), "hipSetDevice");
+            const char* aw = "exchange";
+            const int ra = be.await(be.self, in.stream[k], in.comms[k], &aw);
+            if (ra) { where = aw; return ra; }
+        }
     } else if (in.mode == RTIOW_GATHER_HOST) {
         // last resort: blocking copies through the host, rank by rank (every rank's render awaited first; stream 0 holds every block at the end)
         for (int k = 0; k < in.n; ++k) {
@@ -182,6 +201,15 @@ int run_gather_schedule(const GatherInputs& in, const GatherBackend& be, const c
                 GB(be.stream_wait_event(be.self, s0, in.done[k]), "hipStreamWaitEvent");
             }
         }
+        // completion: the streams that carry a copy across devices, then stream 0
+        for (int k = in.n - 1; k >= 0; --k) {
+            const bool across = k != 0 && in.dev[k] != in.dev[0] && (size_t)in.rows[k] * in.W * 3 != 0;
+            if (!across && k != 0) continue;
+            GB(be.set_device(be.self, in.dev[k]), "hipSetDevice");
+            const char* aw = "exchange";
+            const int ra = be.await(be.self, in.stream[k], nullptr, &aw);
+            if (ra) { where = aw; return ra; }
+        }
     }
     GB(be.set_device(be.self, in.dev[0]), "hipSetDevice");
 #undef GB
@@ -199,18 +227,28 @@ int run_gather_with_fallback(GatherInputs& in, const GatherBackend& be, bool fal
         where = "";
         const int rc = run_gather_schedule(in, be, where);
         if (rc == 0) return 0;
-        if (!fallback || in.mode == RTIOW_GATHER_HOST) return rc;
+        if (!fallback || in.mode == RTIOW_GATHER_HOST) {
+            if (in.mode == RTIOW_GATHER_RCCL) (void)be.abort_comms(be.self);      // a communicator that has failed is in no defined state: aborted, never destroyed
+            return rc;
+        }
         const int next = in.mode == RTIOW_GATHER_RCCL ? RTIOW_GATHER_PEER : RTIOW_GATHER_HOST;
         if (!attempts.empty()) attempts += "; ";
         attempts += std::string(in.mode == RTIOW_GATHER_RCCL ? "RCCL" : "peer copies") + " failed at gather time in " + where + " (" + describe(rc, where) + "), fell back to " +
                     (next == RTIOW_GATHER_PEER ? "peer copies" : "host-staged copies");
+        if (in.mode == RTIOW_GATHER_RCCL) (void)be.abort_comms(be.self);      // its kernels must not be left waiting for a peer when the devices are drained
         (void)be.drain(be.self, in.n, in.dev);
         in.mode = next;
     }
 }
 
 // The real table.  self = the group's RcclApi (null entries are never reached in peer mode).
-struct HipBackendSelf { RcclApi* rccl; int last_nccl; std::vector<unsigned char>* bounce; };
+struct HipBackendSelf { RcclApi* rccl; int last_nccl; std::vector<unsigned char>* bounce; std::vector<ncclComm_t>* comms; bool* rccl_dead; };
+// How long the completion phase waits for a stream before it calls the exchange stalled (RTIOW_GATHER_TIMEOUT_MS; the exchange of a 1080p frame takes < 0.1 ms).
+inline double gather_timeout_ms() {
+    const char* e = getenv("RTIOW_GATHER_TIMEOUT_MS");
+    const double v = e ? atof(e) : 0.0;
+    return v > 0 ? v : 20000.0;
+}
 GatherBackend hip_backend(HipBackendSelf* self) {
     GatherBackend b;
     b.self = self;
@@ -235,6 +273,35 @@ GatherBackend hip_backend(HipBackendSelf* self) {
         if (e == hipSuccess) e = hipMemcpyAsync(dst, h->bounce->data(), bytes, hipMemcpyHostToDevice, dst_stream);
         if (e == hipSuccess) e = hipStreamSynchronize(dst_stream);      // the bounce buffer is reused by the next rank
         return (int)e; };
+    b.await = [](void* p, hipStream_t s, void* comm, const char** where) {
+        auto* h = (HipBackendSelf*)p;
+        const auto t0 = std::chrono::steady_clock::now();
+        const double limit = gather_timeout_ms();
+        for (unsigned spins = 0;; ++spins) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) { *where = "hipStreamQuery (exchange)"; return (int)q; }
+            if (comm && h->rccl->CommGetAsyncError) {
+                ncclResult_t ae = ncclSuccess;
+                const ncclResult_t r = h->rccl->CommGetAsyncError((ncclComm_t)comm, &ae);
+                if (r != ncclSuccess || (ae != ncclSuccess && ae != ncclInProgress)) { *where = "ncclCommGetAsyncError"; return h->last_nccl = (int)(r != ncclSuccess ? r : ae); }
+            }
+            if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > limit) { *where = "hipStreamQuery (exchange stalled past RTIOW_GATHER_TIMEOUT_MS)"; return (int)hipErrorNotReady; }
+            if (spins > 2000) std::this_thread::yield();
+        }
+        if (comm && h->rccl->CommGetAsyncError) {           // a stream can drain although its communicator has recorded an error
+            ncclResult_t ae = ncclSuccess;
+            if (h->rccl->CommGetAsyncError((ncclComm_t)comm, &ae) == ncclSuccess && ae != ncclSuccess && ae != ncclInProgress) { *where = "ncclCommGetAsyncError"; return h->last_nccl = (int)ae; }
+        }
+        return 0; };
+    b.abort_comms = [](void* p) {
+        auto* h = (HipBackendSelf*)p;
+        if (h->comms) {
+            for (ncclComm_t& c : *h->comms) if (c) { if (h->rccl->CommAbort) (void)h->rccl->CommAbort(c); c = nullptr; }   // aborted communicators are gone: never destroyed again
+            h->comms->clear();
+        }
+        if (h->rccl_dead) *h->rccl_dead = true;
+        return 0; };
     b.drain = [](void*, int ndev, const int* dev) {
         for (int k = 0; k < ndev; ++k) { if (hipSetDevice(dev[k]) == hipSuccess) (void)hipDeviceSynchronize(); (void)hipGetLastError(); }
         (void)hipSetDevice(dev[0]); (void)hipGetLastError();
@@ -257,6 +324,7 @@ struct rtiow_group_s {
     int gather_requested = RTIOW_GATHER_AUTO, gather_mode = 0;   // resolved at the first gather: RTIOW_GATHER_RCCL | RTIOW_GATHER_PEER
     RcclApi rccl;
     std::vector<ncclComm_t> comms;
+    bool rccl_dead = false;                     // RCCL failed at gather time: its communicators were aborted, the group never asks it again
     int rccl_version = 0;
     std::string transport_note;                 // why auto mode fell back, if it did (at creation / first gather, or at gather time)
     std::vector<unsigned char> bounce;          // RTIOW_GATHER_HOST: the host bounce buffer
@@ -547,7 +615,7 @@ int rtiow_group_gather(rtiow_group g) {
         in.n = g->n; in.mode = g->gather_mode; in.W = g->W; in.fp64 = g->precision == 64;
         in.dev = g->dev.data(); in.rows = g->rows.data(); in.offsets = g->host_offsets.data(); in.fb = fb.data(); in.staged = g->staged;
         in.stream = g->stream.data(); in.done = g->done.data(); in.g0 = g->g0; in.comms = comms.data();
-        HipBackendSelf self{&g->rccl, 0, &g->bounce};
+        HipBackendSelf self{&g->rccl, 0, &g->bounce, &g->comms, &g->rccl_dead};
         const char* where = "";
         std::string attempts;
         auto describe = [g](int rc, const char* w) { return std::string(w[0] == 'n' ? g->rccl.GetErrorString((ncclResult_t)rc) : hipGetErrorString((hipError_t)rc)); };
@@ -622,6 +690,10 @@ const char* rtiow_group_transport_note(rtiow_group g) { return g ? g->transport_
 //   op 6 group_start       op 7 group_end
 //   op 8 send              a = source rank (by its framebuffer), b = count (elements), c = fp64, d = peer, e = communicator id, f = stream id
 //   op 9 recv              a = dst byte offset, b = count, c = fp64, d = peer, e = communicator id, f = stream id
+//   op 10 stream_sync      a = stream id            op 11 copy_via_host  a = dst byte offset, b = source rank, c = bytes, d = dst stream, e = dst device, f = src device
+//   op 12 (closing record of a fallback run) a = transport that carried the image, b = length of the note
+//   op 13 drain            a = devices              op 15 abort_comms
+//   op 14 await            a = stream id, b = communicator id (0: none) -- the completion phase: "enqueue ok, completion fails" is a failure HERE
 // ids: stream of rank k = 1 + k; event done[k] = 100 + k, g0 = 99; communicator of rank k = 200 + k.
 // fail_at >= 0 makes the (fail_at)-th call return an error (the schedule must stop, or -- inside an RCCL group --
 // still close the group).  Returns the number of records, or a negative RTIOW_E_* code.
@@ -670,6 +742,8 @@ int rtiow_debug_gather_schedule(int n, const int* devices, const int* rows, int 
     b.copy_via_host = [](void* p, void* dst, int dd, hipStream_t ds, const void* src, int sd, size_t bytes) {
         auto* r = (Rec*)p; r->put(11, (char*)dst - r->staged, r->rank_of(src), (int64_t)bytes, (int64_t)(uintptr_t)ds, dd, sd); return r->hit(); };
     b.drain = [](void* p, int ndev, const int*) { auto* r = (Rec*)p; r->put(13, ndev); return 0; };      // never fails, not counted by fail_at
+    b.await = [](void* p, hipStream_t s, void* comm, const char** where) { auto* r = (Rec*)p; r->put(14, (int64_t)(uintptr_t)s, (int64_t)(uintptr_t)comm); *where = "await"; return r->hit(); };
+    b.abort_comms = [](void* p) { auto* r = (Rec*)p; r->put(15); return 0; };                             // never fails, not counted by fail_at
     (void)id;
     GatherInputs in;
     in.n = n; in.mode = mode; in.W = W; in.fp64 = precision == 64;
@@ -682,7 +756,8 @@ int rtiow_debug_gather_schedule(int n, const int* devices, const int* rows, int 
         rec.device = -1;
         rec.put(12, in.mode, (int64_t)attempts.size());
     } else {
-        *schedule_rc = run_gather_schedule(in, b, where);
+        std::string attempts;          // a transport requested outright: the same entry rtiow_group_gather takes, without the chain
+        *schedule_rc = run_gather_with_fallback(in, b, false, where, attempts, [](int, const char*) { return std::string("injected"); });
     }
     (void)es;
     const size_t nrec = rec.v.size() / 8;

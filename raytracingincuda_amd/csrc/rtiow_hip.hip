@@ -159,6 +159,16 @@ int rtiow_create(int device, int precision, rtiow_handle* out) {
         h->stats.clock_mhz = prop.clockRate / 1000;
     }
     h->stats.num_cus = h->num_cus;
+    // the clock stamps of the render launches (ColdParams::clock_stamps): 64 bytes of pinned host memory the device writes to; without them
+    // (allocation refused) the stats fields stay 0
+    {
+        void* host = nullptr; void* dev = nullptr;
+        if (hipHostMalloc(&host, 8 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dev, host, 0) == hipSuccess) {
+            std::memset(host, 0, 8 * sizeof(unsigned long long));
+            h->clock_stamps = (unsigned long long*)host; h->clock_stamps_dev = (unsigned long long*)dev;
+        } else if (host) (void)hipHostFree(host);
+        (void)hipGetLastError();
+    }
     *out = h;
     return 0;
 }
@@ -170,6 +180,7 @@ int rtiow_destroy(rtiow_handle h) {
     void* bufs[] = {h->geom_a, h->shade_tbl, h->geom_s, h->grid_blob, h->cost_rank, h->rng, h->jump, h->work_counter, h->mid, h->slot_of, h->staged,
                     h->cost, h->order, h->sort_scratch, h->levels, h->rng_low_table, h->fb_external ? nullptr : h->fb};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    if (h->clock_stamps) (void)hipHostFree(h->clock_stamps);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_a) (void)hipEventDestroy(h->ev_a);
@@ -471,6 +482,15 @@ int rtiow_set_schedule(rtiow_handle h, int schedule, int waves_per_simd) {
 int rtiow_get_stats(rtiow_handle h, rtiow_stats* out) {
     if (!h || !out) return RTIOW_E_BADARG;
     *out = h->stats;
+    out->main_clock_mhz = out->prepass_clock_mhz = out->main_wave0_ms = 0;
+    if (h->clock_stamps && !h->render_pending) {
+        // {s_memtime, s_memrealtime (100 MHz)} x {start, end}: prepass [0..3], main launch [4..7]; zeroed before every timed render
+        const volatile unsigned long long* s = h->clock_stamps;
+        auto mhz = [&](int k) { return s[k + 3] > s[k + 1] && s[k + 2] > s[k] ? 100.0 * (double)(s[k + 2] - s[k]) / (double)(s[k + 3] - s[k + 1]) : 0.0; };
+        out->prepass_clock_mhz = h->stats.phases == 2 ? mhz(0) : 0.0;
+        out->main_clock_mhz = mhz(4);
+        if (s[7] > s[5]) out->main_wave0_ms = (double)(s[7] - s[5]) * 1e-5;
+    }
     return 0;
 }
 

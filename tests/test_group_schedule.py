@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 SET_DEVICE, WAIT, RECORD, COPY, COPY_PEER, GROUP_START, GROUP_END, SEND, RECV = range(1, 10)
-STREAM_SYNC, COPY_VIA_HOST, CARRIED_BY, DRAIN = 10, 11, 12, 13
+STREAM_SYNC, COPY_VIA_HOST, CARRIED_BY, DRAIN, AWAIT, ABORT_COMMS = 10, 11, 12, 13, 14, 15
 G0 = 99
 
 
@@ -84,8 +84,16 @@ def test_rccl_schedule_counts_offsets_comms_and_fences(native, n, H, strip, prec
     # blocks tile the staging buffer exactly (rank-major, no gaps, no overlap)
     ends = [off[k] + rows[k] * W * 3 * es for k in live]
     assert [off[k] for k in live][1:] == ends[:-1] and ends[-1] == W * H * 3 * es
+    # ---- completion (sends / receives fail or stall AFTER they were enqueued): every sender's stream is awaited on its device
+    # with its communicator's asynchronous error state, stream 0 (the receives) last
+    tail = rec[i_end + 1:-1]
+    awaited = [k for k in range(n - 1, -1, -1) if rows[k] > 0 or k == 0]
+    assert [r[0] for r in tail] == [SET_DEVICE, AWAIT] * len(awaited)
+    for j, k in enumerate(awaited):
+        sd, aw = tail[2 * j], tail[2 * j + 1]
+        assert sd[2] == devices[k] and aw[1] == devices[k] and (aw[2], aw[3]) == (stream(k), comm(k))
     # ---- the schedule ends with device 0 current (the caller launches the de-interleave there)
-    assert rec[-1][:3] == (SET_DEVICE, rec[-2][1] if len(rec) > 1 else -1, 0) and ops[i_end + 1:] == [SET_DEVICE]
+    assert rec[-1][:3] == (SET_DEVICE, rec[-2][1] if len(rec) > 1 else -1, 0)
     assert COPY not in ops and COPY_PEER not in ops
 
 
@@ -104,7 +112,8 @@ def test_peer_schedule_event_choreography(native, prec):
     i_g0 = next(i for i, r in enumerate(rec) if r[0] == RECORD and r[2] == G0)
     assert [(r[2], r[3]) for r in rec[:i_g0] if r[0] == WAIT] == [(stream(0), done(k)) for k in range(1, n)]
     off = offsets_bytes(rows, W, es)
-    body = rec[i_g0 + 1:-1]
+    i_aw = ops.index(AWAIT) - 1                     # the completion phase starts with the set-device in front of the first await
+    body = rec[i_g0 + 1:i_aw]
     pos = 0
     for k in range(n):
         nbytes = rows[k] * W * 3 * es
@@ -123,6 +132,12 @@ def test_peer_schedule_event_choreography(native, prec):
             assert w0[0] == WAIT and (w0[2], w0[3]) == (stream(0), done(k)) and w0[1] == 0              # stream 0 sees the block
             pos += 6
     assert pos == len(body) and rec[-1][0] == SET_DEVICE and rec[-1][2] == 0
+    # completion: every stream that carries a copy ACROSS devices is awaited on its device (no communicator), then stream 0
+    tail = rec[i_aw:-1]
+    across = [k for k in range(n - 1, 0, -1) if devices[k] != devices[0] and rows[k] > 0] + [0]
+    assert [r[0] for r in tail] == [SET_DEVICE, AWAIT] * len(across)
+    for j, k in enumerate(across):
+        assert tail[2 * j][2] == devices[k] and tail[2 * j + 1][1:4] == (devices[k], stream(k), 0)
 
 
 def test_ranks_without_rows_take_no_part(native):
@@ -145,7 +160,7 @@ def test_single_rank_group_sends_to_itself(native):
     """N = 1 is what a one-GPU box executes on hardware (tests/test_group.py): rank 0 sends to itself inside the group."""
     rec, rc = native.debug_gather_schedule([0], [48], 100, 32, native.GATHER_RCCL)
     assert rc == 0
-    assert [r[0] for r in rec] == [SET_DEVICE, RECORD, GROUP_START, SEND, RECV, GROUP_END, SET_DEVICE]
+    assert [r[0] for r in rec] == [SET_DEVICE, RECORD, GROUP_START, SEND, RECV, GROUP_END, SET_DEVICE, AWAIT, SET_DEVICE]
     assert rec[3][2:] == (0, 48 * 100 * 3, 0, 0, comm(0), stream(0)) and rec[4][2:] == (0, 48 * 100 * 3, 0, 0, comm(0), stream(0))
 
 
@@ -158,14 +173,15 @@ def test_a_failing_call_stops_the_schedule_and_closes_the_group(native):
         ops = [r[0] for r in rec]
         assert rc == 999
         if ops_full[fail_at] in (GROUP_START, SEND, RECV):
-            # inside an open RCCL group a failure still closes the group (ncclGroupEnd), and nothing else follows
-            assert ops == ops_full[:fail_at + 1] + [GROUP_END]
+            # inside an open RCCL group a failure still closes the group (ncclGroupEnd); the communicators are then aborted (a communicator
+            # that has failed is in no defined state) and nothing else follows
+            assert ops == ops_full[:fail_at + 1] + [GROUP_END, ABORT_COMMS]
         else:
-            assert ops == ops_full[:fail_at + 1]
+            assert ops == ops_full[:fail_at + 1] + [ABORT_COMMS]
     full, _ = native.debug_gather_schedule([0, 1, 0], [8, 8, 8], W, 32, native.GATHER_PEER)
     for fail_at in range(len(full)):
         rec, rc = native.debug_gather_schedule([0, 1, 0], [8, 8, 8], W, 32, native.GATHER_PEER, fail_at)
-        assert rc == 999 and [r[0] for r in rec] == [r[0] for r in full][:fail_at + 1]
+        assert rc == 999 and [r[0] for r in rec] == [r[0] for r in full][:fail_at + 1]        # no communicators in play: nothing to abort
 
 
 def test_host_staged_schedule(native):
@@ -204,7 +220,7 @@ def test_fallback_chain_at_gather_time(native):
         o = ops(rec)
         i = o.index(DRAIN)
         assert rc == 0 and o.count(DRAIN) == 1 and rec[i][2] == len(devices)
-        head = ops(rccl)[:fail_at + 1] + ([GROUP_END] if ops(rccl)[fail_at] in (GROUP_START, SEND, RECV) else [])
+        head = ops(rccl)[:fail_at + 1] + ([GROUP_END] if ops(rccl)[fail_at] in (GROUP_START, SEND, RECV) else []) + [ABORT_COMMS]   # aborted BEFORE the drain
         assert o[:i] == head and o[i + 1:-1] == ops(peer)
         assert [r[2:] for r in rec[i + 1:-1]] == [r[2:] for r in peer]             # same arguments as a plain peer gather
         assert rec[-1][0] == CARRIED_BY and rec[-1][2] == native.GATHER_PEER and rec[-1][3] > 0   # and a note that says why
@@ -220,6 +236,37 @@ def test_fallback_chain_at_gather_time(native):
     # without the chain (a transport requested outright) the first failure is the result (test_a_failing_call_stops_the_schedule_...)
     rec, rc = native.debug_gather_schedule(devices, rows, W, 32, native.GATHER_RCCL, 3)
     assert rc == 999 and DRAIN not in ops(rec)
+
+
+def test_enqueue_ok_completion_fails(native):
+    """ncclSend / ncclRecv / ncclGroupEnd and hipMemcpyPeerAsync mostly fail or stall asynchronously -- every call returns
+    success and the error (or nothing at all) comes later.  The exchange's COMPLETION is therefore part of the schedule: each stream is awaited
+    (stream query + ncclCommGetAsyncError + a deadline in the real table), and a failure there takes the same chain as a failing call --
+    RCCL's communicators aborted before the devices are drained, then the next transport from the top."""
+    devices, rows, W = [0, 1, 2, 3], [8, 8, 8, 8], 32
+    ops = lambda recs: [r[0] for r in recs]
+    rccl, _ = native.debug_gather_schedule(devices, rows, W, 32, native.GATHER_RCCL)
+    peer, _ = native.debug_gather_schedule(devices, rows, W, 32, native.GATHER_PEER)
+    host, _ = native.debug_gather_schedule(devices, rows, W, 32, native.GATHER_HOST)
+    awaits = [i for i, r in enumerate(rccl) if r[0] == AWAIT]
+    assert len(awaits) == 4 and all(i > ops(rccl).index(GROUP_END) for i in awaits)          # every call of the group has returned success by then
+    for fail_at in awaits:
+        rec, rc = native.debug_gather_schedule(devices, rows, W, 32, native.GATHER_RCCL, fail_at, fallback=True)
+        o = ops(rec)
+        i = o.index(DRAIN)
+        assert rc == 0 and o[:i] == ops(rccl)[:fail_at + 1] + [ABORT_COMMS] and o[i + 1:-1] == ops(peer) and rec[-1][2] == native.GATHER_PEER
+        # requested outright: the failure is the call's, the communicators are aborted all the same
+        rec, rc = native.debug_gather_schedule(devices, rows, W, 32, native.GATHER_RCCL, fail_at)
+        assert rc == 999 and ops(rec) == ops(rccl)[:fail_at + 1] + [ABORT_COMMS]
+    pawaits = [i for i, r in enumerate(peer) if r[0] == AWAIT]
+    assert len(pawaits) == 4
+    for fail_at in pawaits:
+        rec, rc = native.debug_gather_schedule(devices, rows, W, 32, native.GATHER_PEER, fail_at, fallback=True)
+        o = ops(rec)
+        i = o.index(DRAIN)
+        assert rc == 0 and ABORT_COMMS not in o and o[:i] == ops(peer)[:fail_at + 1] and o[i + 1:-1] == ops(host) and rec[-1][2] == native.GATHER_HOST
+    # both asynchronous failures in one frame: RCCL's completion fails, then the peer copies' completion fails: the host path carries the image
+    assert AWAIT not in ops(host)
 
 
 def test_schedule_hook_rejects_bad_arguments(native):

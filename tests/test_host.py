@@ -32,7 +32,7 @@ def test_c_abi_exports_every_declared_symbol(native):
         assert getattr(hip, s) is not None
     for s in host_decl:
         assert getattr(host, s) is not None
-    assert hip.rtiow_abi_version() == native.ABI_VERSION == 5
+    assert hip.rtiow_abi_version() == native.ABI_VERSION == 6
     # exported from the shared objects with C linkage
     syms = subprocess.run(["nm", "-D", "--defined-only", paths["hip"]], capture_output=True, text=True, check=True).stdout
     for s in hip_decl:
