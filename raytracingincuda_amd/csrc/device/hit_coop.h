@@ -46,7 +46,28 @@ __device__ __forceinline__ void hit_world_solo(const RenderParams<float>& p, con
     const LoopRay<float> r = make_loop_ray(ox, oy, oz, dx, dy, dz, ra);
     float best = __builtin_huge_valf();
     int best_idx = -1;
-    for (int s = lane * 4; s < p.n_padded; s += 256) sphere_trip<float>(gm, s, r, best, best_idx);
+#ifndef RTIOW_SOLO_ONE_FINISH
+#define RTIOW_SOLO_ONE_FINISH 1
+#endif
+    for (int s = lane * 4; s < p.n_padded; s += 256) {
+        if (!RTIOW_SOLO_ONE_FINISH) { sphere_trip<float>(gm, s, r, best, best_idx); continue; }
+        // One finishing instance per round instead of the trip's four guarded ones: the ray's handful of candidates sit in different
+        // lanes AND at different positions of their lanes' trips (the ground is sphere 0 = lane 0, position 0; a small sphere anywhere),
+        // so the four sites ran one after the other, each for one lane -- on the critical path of a lone ray.  Here every lane takes its
+        // own lowest pending candidate per round (index order within the lane, which is what the strict `root < closest` needs), and a
+        // round is ONE pre-test + IEEE block for all of them: rounds = the most candidates any lane holds, almost always one.
+        const Trip<float> t = trip_discriminants(gm, s, r);
+        unsigned pend = (t.d0 >= 0.0f ? 1u : 0u) | (t.d1 >= 0.0f ? 2u : 0u) | (t.d2 >= 0.0f ? 4u : 0u) | (t.d3 >= 0.0f ? 8u : 0u);
+        while (__builtin_amdgcn_ballot_w64(pend != 0) != 0) {
+            if (pend != 0) {
+                const int k = __builtin_ctz(pend);
+                pend &= pend - 1;
+                const float hk = k == 0 ? t.h0 : (k == 1 ? t.h1 : (k == 2 ? t.h2 : t.h3));
+                const float dk = k == 0 ? t.d0 : (k == 1 ? t.d1 : (k == 2 ? t.d2 : t.d3));
+                finish_sphere_test<float>(s + k, hk, dk, r.a, best, best_idx);
+            }
+        }
+    }
     // Few lanes hold a hit at all (the ray meets a handful of spheres): walk those lanes with readlanes -- a short
     // scalar loop -- instead of the 64-lane DPP minimum, which is ~60 dependent instructions of pure latency here.
     const unsigned long long holders = __builtin_amdgcn_ballot_w64(best_idx >= 0);

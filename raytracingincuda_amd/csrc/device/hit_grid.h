@@ -115,6 +115,14 @@ __device__ __forceinline__ void cell_tests(const T* aos, unsigned rec_lo, unsign
     }
 }
 
+// v_min_f32 without the canonicalising v_max_f32 x, x the compiler puts in front of fminf's operands (IEEE minNum quiets signalling NaNs): the walk's
+// parameters are never signalling NaNs, and a quiet NaN is returned or dropped as v_min_f32 does it either way (a NaN ray never reaches the walk).
+__device__ __forceinline__ float raw_min(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Clip of o + t d against [lo, hi] on one axis, folded into [t0, t1].  Raw reciprocal: see eps above.
 // Returns the raw reciprocal of d it used (0 for a parallel ray): the walk steps with the same values.
 __device__ __forceinline__ float clip_axis(float o, float d, float lo, float hi, float& t0, float& t1) {
@@ -210,7 +218,7 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
         bool walking = near && crosses;
         if (__builtin_amdgcn_ballot_w64(walking) == 0) { REGION_END(walk, RG_GRID_WALK); return; }
         const T* aos = sizeof(T) == 4 ? reinterpret_cast<const T*>(smem_raw + g.aos_offset) : lds_exact;
-        const uint2* cells = reinterpret_cast<const uint2*>(smem_raw + g.cells_offset);
+        const uint2* cells = reinterpret_cast<const uint2*>(smem_raw + g.cells_offset); (void)cells;
         const unsigned pad2 = (unsigned)p.n * 0x10001u;     // a cell record's upper word when slots 2 and 3 are pads
         const float px = __builtin_fmaf(t0, dx, ox), pz = __builtin_fmaf(t0, dz, oz);
         int cx = (int)__builtin_floorf(px * g.inv_cell), cz = (int)__builtin_floorf(pz * g.inv_cell);
@@ -222,6 +230,48 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
         int step_no = 0;                                   // which step of its walk the wave is in (instrumented build: profiles/r04/path_stats_walk_steps*.json)
         if (walking) PATH_STAT(PS_WALK);
 #endif
+#ifndef RTIOW_DDA_INCREMENTAL
+#define RTIOW_DDA_INCREMENTAL 1
+#endif
+#if RTIOW_DDA_INCREMENTAL
+        // The classic incremental form (round 5): the parameters at which the ray leaves the current cell, per axis, are carried and ADVANCED by
+        // cell * |1 / d| on the axis that steps, and the cell record's LDS address by +-8 bytes / +-8 nx bytes -- 18 vector instructions a step instead
+        // of 30 (closed form: two int -> float conversions, two boundary products, the address from cz * nx + cx with a quarter-rate integer
+        // multiply).  The advanced parameters differ from the closed form's by one rounding per step taken: after k steps at most k ulps of the
+        // parameter, i.e. a position error of k 2^-24 of the distance walked -- the walk takes at most nx + nz <= 128 steps (plan_grid: nx nz <= 4096),
+        // so at most 2^-17 of the largest coordinate in play, half of the eps = 2^-16 L every registration is widened by (the clip's own roundings
+        // are a few ulps).  Which cell a ray is said to be in near a boundary is therefore still decided within eps of the truth, which is all the
+        // exactness argument above asks of the walk.
+        const float dtx = step_x ? g.cell * __builtin_fabsf(inv_dx) : 0.0f, dtz = step_z ? g.cell * __builtin_fabsf(inv_dz) : 0.0f;
+        float tx = step_x ? ((float)(cx + (sx > 0 ? 1 : 0)) * g.cell - ox) * inv_dx : __builtin_huge_valf();
+        float tz = step_z ? ((float)(cz + (sz > 0 ? 1 : 0)) * g.cell - oz) * inv_dz : __builtin_huge_valf();
+        int cell_at = (cz * g.nx + cx) * 8;                                   // byte offset of the cell's record
+        const int dax = sx * 8, daz = sz * g.nx * 8;
+        const unsigned char* cells_b = smem_raw + g.cells_offset;
+        while (__builtin_amdgcn_ballot_w64(walking) != 0) {
+#ifdef RTIOW_PATH_STATS
+            ++step_no;
+#endif
+            if (walking) {
+                PATH_STAT(PS_GRID_STEP);
+#ifdef RTIOW_PATH_STATS
+                path_stat(step_no == 1 ? PS_STEP_1 : step_no == 2 ? PS_STEP_2 : step_no == 3 ? PS_STEP_3 : step_no == 4 ? PS_STEP_4 : step_no <= 8 ? PS_STEP_5_8 : PS_STEP_9_UP);
+#endif
+                const uint2 rec = *reinterpret_cast<const uint2*>(cells_b + cell_at);
+                if (rec.x != 0xffffffffu) cell_tests<T>(aos, rec.x, rec.y, pad2, O, D, a, closest, hit, fdc);
+                const float tnext = raw_min(tx, tz);
+                const float tend = raw_min(t1, (float)closest);                    // (float) rounds to nearest: covered by eps
+                if (tnext >= tend) walking = false;                               // leaves the slab / the grid, or a nearer hit is known
+                else {
+                    const bool x_first = tx <= tz;
+                    cx += x_first ? sx : 0; cz += x_first ? 0 : sz;
+                    cell_at += x_first ? dax : daz;
+                    tx += x_first ? dtx : 0.0f; tz += x_first ? 0.0f : dtz;
+                    if ((unsigned)cx >= (unsigned)g.nx || (unsigned)cz >= (unsigned)g.nz) walking = false;
+                }
+            }
+        }
+#else
         while (__builtin_amdgcn_ballot_w64(walking) != 0) {
 #ifdef RTIOW_PATH_STATS
             ++step_no;
@@ -246,6 +296,7 @@ __device__ __forceinline__ void hit_world_grid(const RenderParams<T>& p, const T
                 }
             }
         }
+#endif
         REGION_END(walk, RG_GRID_WALK);
     };
     if (fd.on) direct_list_and_walk(std::true_type{});

@@ -116,4 +116,17 @@ __device__ __forceinline__ void finish_pixel(const COLD& c, size_t lp, const Pat
     }
 }
 
+// Clock warm-up (study knob RTIOW_CLOCK_WARMUP_US, profiles/r05/cold_process_study.md): every SIMD busy with dependent FMAs for `ticks` of the
+// 100 MHz counter.  A process's first render finds the chip at ~2.24 GHz and its second at ~2.34 (DVFS ramps under load); the reference's own
+// set-up ends with a long kernel (curand_init with a subsequence per pixel, main.cu:326-330), ours with a 0.6 ms one.
+__global__ void __launch_bounds__(256) clock_warmup_kernel(unsigned long long ticks, float* sink) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    float a = 1.0f + 1e-7f * (float)threadIdx.x, b = 0.5f;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) { a = __builtin_fmaf(a, 0.999f, 1e-3f); b = __builtin_fmaf(b, 0.998f, 2e-3f); }
+    }
+    if (a + b == 12345.678f) sink[0] = a;
+}
+
 }  // namespace

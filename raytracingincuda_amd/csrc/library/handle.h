@@ -59,6 +59,8 @@ struct rtiow_handle_s {
     int last_count_blocks = 0, last_count_waves_per_block = 0;
     size_t timeline_cap_waves = 0;            // waves the debug timeline buffer holds
     unsigned int* work_counter = nullptr;
+    int warmup_us = 0;                               // RTIOW_CLOCK_WARMUP_US: busy kernel in front of the handle's FIRST timed render (before its start event), see clock_warmup_kernel
+    bool warmed = false;
     unsigned long long* clock_stamps = nullptr;      // pinned + mapped host memory, 8 words: {memtime, realtime} x {start, end} of the prepass [0..3] and the main launch [4..7]
     unsigned long long* clock_stamps_dev = nullptr;  // its device address
     unsigned long long* timeline = nullptr;   // debug: set only during rtiow_debug_timeline

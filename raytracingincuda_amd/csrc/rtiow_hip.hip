@@ -159,6 +159,7 @@ int rtiow_create(int device, int precision, rtiow_handle* out) {
         h->stats.clock_mhz = prop.clockRate / 1000;
     }
     h->stats.num_cus = h->num_cus;
+    if (const char* w = getenv("RTIOW_CLOCK_WARMUP_US")) { const int v = atoi(w); h->warmup_us = v > 0 && v <= 50000 ? v : 0; }
     // the clock stamps of the render launches (ColdParams::clock_stamps): 64 bytes of pinned host memory the device writes to; without them
     // (allocation refused) the stats fields stay 0
     {
@@ -313,6 +314,11 @@ static int render_begin(rtiow_handle_s* h, int T, bool timed) {
     if (h->precision == 32) rc = launch_render<float>(h, h->cam32, bx, by, wave_tiles, nullptr, true);
     else rc = launch_render<double>(h, h->cam64, bx, by, wave_tiles, nullptr, true);
     if (rc) return rc;
+    if (timed && h->warmup_us > 0 && !h->warmed) {        // study knob: the chip's clock ramps under load; this load comes BEFORE the start event
+        hipLaunchKernelGGL(clock_warmup_kernel, dim3((unsigned)h->num_cus * 8u), dim3(256), 0, h->stream, (unsigned long long)h->warmup_us * 100ull, (float*)h->work_counter);
+        HIP_TRY(h, hipGetLastError());
+        h->warmed = true;
+    }
     if (timed) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));                         // main.cu:334
     h->time_phases = timed;
     if (h->precision == 32) rc = launch_render<float>(h, h->cam32, bx, by, wave_tiles);

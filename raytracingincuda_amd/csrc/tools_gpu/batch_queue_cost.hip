@@ -66,10 +66,16 @@ __device__ __forceinline__ void body(float (&w)[WORDS]) {
 }
 
 // counters[0] batches, [1] records processed, [2] pop attempts that found every queue empty, [3] CAS retries, [4] valid-bit spins, [5] waves stopped by GUARD (must be 0)
-template <int BODY>
+template <int BODY, bool STAMPS>
 __global__ void __launch_bounds__(1024) queue_kernel(unsigned long long* counters, float* sink) {
+#define STAMP() (STAMPS ? __builtin_amdgcn_s_memtime() : 0ull)
+#define STAMP_LANE(v) do { if (STAMPS) v = __builtin_amdgcn_s_memtime(); } while (0)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Lds& L = *reinterpret_cast<Lds*>(smem);
+    // LDS-qualified view: every access below must be a ds_* instruction.  (Run 1 of this probe went through a generic `Lds&`: its volatile
+    // reads of the counters and ring entries compiled to flat_load / flat_store on the LDS aperture, 4000+ cycles per batch --
+    // profiles/r05/batch_queue_cost_run1_flat_ops.json, kept as a record of the mistake, not as a result.)
+    typedef __attribute__((address_space(3))) Lds LdsT;
+    LdsT& L = *(LdsT*)smem;
     const int lane = lane_id();
     for (int r = threadIdx.x; r < NREC; r += blockDim.x) {
         for (int k = 0; k < WORDS / 4; ++k) {
@@ -86,10 +92,12 @@ __global__ void __launch_bounds__(1024) queue_kernel(unsigned long long* counter
     if (threadIdx.x == 0) L.retired = 0;
     __syncthreads();                                             // the ONLY barrier: before the first batch
     unsigned long long n_batches = 0, n_records = 0, n_empty = 0, n_retry = 0, n_spin = 0;
+    unsigned long long c_pick = 0, c_load = 0, c_body = 0, c_store = 0, c_push = 0;      // s_memtime cycles of a wave per section (STAMPS builds)
     float keep = 0;
     unsigned long long n_guard = 0;
     for (int trip = 0;; ++trip) {
         if (trip >= GUARD) { n_guard = 1; break; }
+        const unsigned long long s0 = STAMP();
         // ---- pick the fullest queue and claim up to 64 of its entries: lane 0, one compare-and-swap
         int q = 0, n = 0;
         uint32_t h = 0;
@@ -97,7 +105,7 @@ __global__ void __launch_bounds__(1024) queue_kernel(unsigned long long* counter
             bool got = false;
             for (int tries = 0; tries < 64 && !got; ++tries) {
                 n = 0;
-                const u4 hd = *reinterpret_cast<volatile u4*>(L.head), tl = *reinterpret_cast<volatile u4*>(L.tail);
+                const u4 hd = *(volatile __attribute__((address_space(3))) u4*)L.head, tl = *(volatile __attribute__((address_space(3))) u4*)L.tail;
                 const uint32_t av[NQ] = {tl.x - hd.x, tl.y - hd.y, tl.z - hd.z, tl.w - hd.w};
                 const uint32_t hs[NQ] = {hd.x, hd.y, hd.z, hd.w};
                 q = 0;
@@ -105,7 +113,8 @@ __global__ void __launch_bounds__(1024) queue_kernel(unsigned long long* counter
                 n = av[q] < 64u ? (int)av[q] : 64;
                 if (n == 0) break;
                 h = hs[q];
-                if (atomicCAS(&L.head[q], h, h + (uint32_t)n) == h) got = true;
+                uint32_t expect = h;
+                if (__hip_atomic_compare_exchange_strong(&L.head[q], &expect, h + (uint32_t)n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) got = true;
                 else ++n_retry;
             }
             if (!got) n = 0;                                      // every queue empty, or 64 lost races in a row: poll again
@@ -113,17 +122,19 @@ __global__ void __launch_bounds__(1024) queue_kernel(unsigned long long* counter
         n = __builtin_amdgcn_readfirstlane(n); q = __builtin_amdgcn_readfirstlane(q); h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
         if (n == 0) {
             ++n_empty;
-            if (*reinterpret_cast<volatile uint32_t*>(&L.retired) >= (uint32_t)NREC) break;
+            if (__hip_atomic_load(&L.retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (uint32_t)NREC) break;
             __builtin_amdgcn_s_sleep(2);
             continue;
         }
         ++n_batches; n_records += (unsigned)n;
+        const unsigned long long s1 = STAMP();
         // ---- the batch: indices, records
         const bool on = lane < n;
+        unsigned long long s2 = 0, s3 = 0;
         int idx = 0;
         float w[WORDS];
         if (on) {
-            volatile uint16_t* e = &L.ring[q][(h + (uint32_t)lane) & (RING - 1)];
+            volatile __attribute__((address_space(3))) uint16_t* e = &L.ring[q][(h + (uint32_t)lane) & (RING - 1)];
             uint16_t v;
             while (((v = *e) & 0x8000) == 0 && n_spin < 1000000ull) ++n_spin;   // reserved by its pusher, not written yet (bounded: see GUARD)
             *e = 0;
@@ -133,7 +144,9 @@ __global__ void __launch_bounds__(1024) queue_kernel(unsigned long long* counter
                 const u4 v4 = L.rec[idx][k];
                 w[4 * k] = __uint_as_float(v4.x); w[4 * k + 1] = __uint_as_float(v4.y); w[4 * k + 2] = __uint_as_float(v4.z); w[4 * k + 3] = __uint_as_float(v4.w);
             }
+            STAMP_LANE(s2);
             body<BODY>(w);
+            STAMP_LANE(s3);
         }
         // ---- next phase of every path, records back, push
         int nq = -1;
@@ -149,25 +162,33 @@ __global__ void __launch_bounds__(1024) queue_kernel(unsigned long long* counter
             nq = left == 0 ? -1 : (int)(g >> 30);
             keep += w[0];
         }
+        const unsigned long long s4 = STAMP();
         const unsigned long long m_ret = __builtin_amdgcn_ballot_w64(on && nq < 0);
-        if (m_ret != 0 && lane == 0) atomicAdd(&L.retired, (uint32_t)__builtin_popcountll(m_ret));
+        if (m_ret != 0 && lane == 0) __hip_atomic_fetch_add(&L.retired, (uint32_t)__builtin_popcountll(m_ret), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
         for (int k = 0; k < NQ; ++k) {
             const unsigned long long m = __builtin_amdgcn_ballot_w64(nq == k);
             if (m == 0) continue;
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&L.tail[k], (uint32_t)__builtin_popcountll(m));
+            if (lane == 0) base = __hip_atomic_fetch_add(&L.tail[k], (uint32_t)__builtin_popcountll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
             if (nq == k) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 L.ring[k][(base + rank) & (RING - 1)] = (uint16_t)(idx | 0x8000);
             }
         }
+        if (STAMPS) {
+            const unsigned long long s5 = STAMP();
+            s2 = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(unsigned)s2) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(s2 >> 32)) << 32);
+            s3 = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(unsigned)s3) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(s3 >> 32)) << 32);
+            c_pick += s1 - s0; c_load += s2 - s1; c_body += s3 - s2; c_store += s4 - s3; c_push += s5 - s4;
+        }
     }
     if (keep == 12345.678f) sink[0] = keep;
     if (lane == 0) {
         atomicAdd(&counters[0], n_batches); atomicAdd(&counters[1], n_records); atomicAdd(&counters[2], n_empty);
         atomicAdd(&counters[3], n_retry); atomicAdd(&counters[5], n_guard);
+        if (STAMPS) { atomicAdd(&counters[6], c_pick); atomicAdd(&counters[7], c_load); atomicAdd(&counters[8], c_body); atomicAdd(&counters[9], c_store); atomicAdd(&counters[10], c_push); }
     }
     unsigned long long s = n_spin;
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -187,21 +208,22 @@ __global__ void __launch_bounds__(1024) baseline_kernel(int per_wave, float* sin
     if (w[0] + w[1] == 12345.678f) sink[0] = w[0];
 }
 
-struct Result { double ms_queue, ms_base, batches, records, empty_polls, cas_retries, spins, guard; };
+struct Result { double ms_queue, ms_base, batches, records, empty_polls, cas_retries, spins, guard; double sec[5]; };
 
 template <int BODY>
 Result run(int waves_per_wg, int cus) {
     unsigned long long* dc; float* sink;
-    hipMalloc(&dc, 6 * sizeof(unsigned long long)); hipMalloc(&sink, 4);
-    hipFuncSetAttribute((const void*)queue_kernel<BODY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds));
+    hipMalloc(&dc, 11 * sizeof(unsigned long long)); hipMalloc(&sink, 4);
+    hipFuncSetAttribute((const void*)queue_kernel<BODY, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds));
+    hipFuncSetAttribute((const void*)queue_kernel<BODY, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds));
     hipFuncSetAttribute((const void*)baseline_kernel<BODY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int threads = 64 * waves_per_wg;
-    Result r{1e30, 1e30, 0, 0, 0, 0, 0, 0};
+    Result r{1e30, 1e30, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0, 0}};
     for (int rep = 0; rep < 4; ++rep) {
-        hipMemset(dc, 0, 6 * sizeof(unsigned long long));
+        hipMemset(dc, 0, 11 * sizeof(unsigned long long));
         hipEventRecord(e0);
-        queue_kernel<BODY><<<cus, threads, sizeof(Lds)>>>(dc, sink);
+        queue_kernel<BODY, false><<<cus, threads, sizeof(Lds)>>>(dc, sink);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (rep > 0 && ms < r.ms_queue) {
@@ -210,6 +232,13 @@ Result run(int waves_per_wg, int cus) {
             r.guard = (double)c[5];
             r.batches = (double)c[0] / cus; r.records = (double)c[1] / cus; r.empty_polls = (double)c[2] / cus; r.cas_retries = (double)c[3] / cus; r.spins = (double)c[4] / cus;
         }
+    }
+    {   // the same kernel with s_memtime stamps around its sections: where a wave's time per batch goes (the stamps cost a little: shares)
+        hipMemset(dc, 0, 11 * sizeof(unsigned long long));
+        queue_kernel<BODY, true><<<cus, threads, sizeof(Lds)>>>(dc, sink);
+        hipDeviceSynchronize();
+        unsigned long long c[11]; hipMemcpy(c, dc, sizeof c, hipMemcpyDeviceToHost);
+        for (int k = 0; k < 5; ++k) r.sec[k] = c[0] ? (double)c[6 + k] / (double)c[0] : 0.0;
     }
     const int per_wave = NREC * TRIPS / 64 / waves_per_wg;
     for (int rep = 0; rep < 4; ++rep) {
@@ -234,9 +263,10 @@ void report(int waves_per_wg, int cus, double hz, bool first) {
     printf("%s{\"body_instructions\": %d, \"waves_per_simd\": %d, \"ms_queue\": %.4f, \"ms_body_only\": %.4f, \"batches_per_workgroup\": %.0f, \"mean_batch_fill\": %.2f, "
            "\"simd_cycles_per_batch\": %.1f, \"simd_cycles_per_64_path_phases\": %.1f, \"simd_cycles_body_only_per_batch\": %.1f, "
            "\"queue_overhead_cycles_per_64_path_phases\": %.1f, \"queue_overhead_instruction_equivalents\": %.1f, \"overhead_over_body\": %.3f, "
-           "\"empty_polls_per_workgroup\": %.0f, \"cas_retries_per_workgroup\": %.0f, \"valid_bit_spins_per_workgroup\": %.0f, \"waves_stopped_by_guard\": %.0f}",
+           "\"empty_polls_per_workgroup\": %.0f, \"cas_retries_per_workgroup\": %.0f, \"valid_bit_spins_per_workgroup\": %.0f, \"waves_stopped_by_guard\": %.0f, "
+           "\"wave_cycles_per_batch_by_section\": {\"pick_and_claim\": %.0f, \"indices_and_records_in\": %.0f, \"body\": %.0f, \"records_out\": %.0f, \"push\": %.0f}}",
            first ? "" : ", ", BODY, waves_per_wg / 4, r.ms_queue, r.ms_base, r.batches, r.records / r.batches, cyc_queue, cyc_queue_per64, cyc_base,
-           cyc_queue_per64 - cyc_base, (cyc_queue_per64 - cyc_base) / 3.87, (cyc_queue_per64 - cyc_base) / cyc_base, r.empty_polls, r.cas_retries, r.spins, r.guard);
+           cyc_queue_per64 - cyc_base, (cyc_queue_per64 - cyc_base) / 3.87, (cyc_queue_per64 - cyc_base) / cyc_base, r.empty_polls, r.cas_retries, r.spins, r.guard, r.sec[0], r.sec[1], r.sec[2], r.sec[3], r.sec[4]);
 }
 
 int main() {

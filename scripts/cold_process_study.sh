@@ -24,12 +24,18 @@ for i in 1 2 3 4 5 6 7 8 9 10; do sleep 2; run idle_2s_before $i; done
 export RTIOW_RENDER_TWICE=1
 for i in 1 2 3 4 5 6 7 8 9 10; do run second_render_of_the_process $i; done
 unset RTIOW_RENDER_TWICE
+#   series D..: back to back, with the clock warm-up knob (RTIOW_CLOCK_WARMUP_US: every SIMD busy for that long in front of the start event)
+for us in 500 1000 2000 4000 8000; do
+  export RTIOW_CLOCK_WARMUP_US=$us
+  for i in 1 2 3 4 5 6 7 8 9 10; do run warmup_${us}us $i; done
+done
+unset RTIOW_CLOCK_WARMUP_US
 # the same three series' summary
 python3 - "$OUT" <<'PY'
 import json, sys
 import statistics as st
 rows = [json.loads(l) for l in open(sys.argv[1])]
-for s in ("back_to_back", "idle_2s_before", "second_render_of_the_process"):
+for s in ("back_to_back", "idle_2s_before", "second_render_of_the_process", "warmup_500us", "warmup_1000us", "warmup_2000us", "warmup_4000us", "warmup_8000us"):
     r = [x["stats"] for x in rows if x["series"] == s]
     ms = [x["render_ms"] for x in r]
     print(json.dumps({"series": s, "render_ms": [round(v, 2) for v in ms], "median": round(st.median(ms), 3), "max": round(max(ms), 3),
