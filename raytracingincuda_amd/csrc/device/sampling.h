@@ -44,6 +44,10 @@ template <class T> __device__ __forceinline__ bool random_unit_vector_rounds(Rng
     return false;
 }
 
+// Pins wave-uniform values in scalar registers at this point of the program (the loads that produce them are issued before it).
+__device__ __forceinline__ void keep_scalar(float& a, float& b, float& c, float& d, float& e, float& f) { asm volatile("" : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e), "+s"(f)); }
+__device__ __forceinline__ void keep_scalar(double& a, double& b, double& c, double& d, double& e, double& f) { asm volatile("" : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e), "+s"(f)); }
+
 // One primary ray: camera.h:145-155 (+ :73-76, vec3.h:109-115).  Also returns the y
 // component of the PRIMARY ray's unit direction, all the sky term needs (camera.h:121).
 template <class T>
@@ -51,6 +55,15 @@ __device__ __forceinline__ void gen_primary(const RenderParams<T>& p, int i, int
                                             V3<T>& O, V3<T>& D, T& sky_uy) {
     PATH_STAT(PS_GEN_PRIMARY);
     const auto& c = cam_of(p);                   // scalar loads from the kernarg segment, here
+#ifndef RTIOW_CAMERA_ONE_FETCH
+#define RTIOW_CAMERA_ONE_FETCH 1
+#endif
+    // The lens vectors are needed only behind the disk's rejection loop, and the compiler fetched them there: a SECOND scalar-memory round trip
+    // per primary ray, ~250 cycles that nothing hides when the wave holds one ray (a lone trip waits 1140 of its 3080 cycles, two of its
+    // waits are these: profiles/r05/lone_trip_counters_scene3.json).  Read here, with the rest of the camera, they arrive while the jitter and the
+    // disk loop draw: six scalar registers live across that loop instead of a stall behind it.
+    T ddux = c.ddu.x, dduy = c.ddu.y, dduz = c.ddu.z, ddvx = c.ddv.x, ddvy = c.ddv.y, ddvz = c.ddv.z;
+    if (RTIOW_CAMERA_ONE_FETCH) keep_scalar(ddux, dduy, dduz, ddvx, ddvy, ddvz);
     T ox = Real<T>::uniform(s) - (T)0.5;
     T oy = Real<T>::uniform(s) - (T)0.5;
     T fi = (T)i + ox, fj = (T)j + oy;
@@ -67,7 +80,8 @@ __device__ __forceinline__ void gen_primary(const RenderParams<T>& p, int i, int
             py = RT_FMA((T)2, u1, (T)-1);
             if (RT_FMA(py, py, px * px) < (T)1) break;
         }
-        org = madd3(py, V3<T>{c.ddv.x, c.ddv.y, c.ddv.z}, madd3(px, V3<T>{c.ddu.x, c.ddu.y, c.ddu.z}, ctr));
+        if (RTIOW_CAMERA_ONE_FETCH) org = madd3(py, V3<T>{ddvx, ddvy, ddvz}, madd3(px, V3<T>{ddux, dduy, dduz}, ctr));
+        else org = madd3(py, V3<T>{c.ddv.x, c.ddv.y, c.ddv.z}, madd3(px, V3<T>{c.ddu.x, c.ddu.y, c.ddu.z}, ctr));
     }
     O = org;
     D = {ps.x - org.x, ps.y - org.y, ps.z - org.z};

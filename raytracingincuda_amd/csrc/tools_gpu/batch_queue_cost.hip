@@ -179,8 +179,8 @@ __global__ void __launch_bounds__(1024) queue_kernel(unsigned long long* counter
         }
         if (STAMPS) {
             const unsigned long long s5 = STAMP();
-            s2 = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(unsigned)s2) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(s2 >> 32)) << 32);
-            s3 = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(unsigned)s3) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(s3 >> 32)) << 32);
+            s2 = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)s2) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(s2 >> 32)) << 32);
+            s3 = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)s3) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(s3 >> 32)) << 32);
             c_pick += s1 - s0; c_load += s2 - s1; c_body += s3 - s2; c_store += s4 - s3; c_push += s5 - s4;
         }
     }

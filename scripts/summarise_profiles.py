@@ -2,11 +2,11 @@
 bench lines, the rocprofv3 kernel-stats table, the per-launch agreement check between rocprofv3 and bench.py's HIP
 events, and the counter records (profiles/pmc_records.json: what `bench.py --pmc committed` reads -- each record
 carries the build id of the library it was measured on).
-Usage: summarise_profiles.py [round_tag]   (default r04; files land in profiles/<round_tag>/)"""
+Usage: summarise_profiles.py [round_tag]   (default r05; files land in profiles/<round_tag>/)"""
 import csv, glob, json, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "final")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 top = os.path.join(root, "profiles")
 dst = os.path.join(top, tag)                      # one directory per round; profiles/pmc_records.json (what bench.py --pmc committed reads) stays at the top
 os.makedirs(dst, exist_ok=True)
@@ -44,6 +44,9 @@ if os.path.exists(os.path.join(src, "pmc_records.json")):
     json.dump(rec, open(os.path.join(top, "pmc_records.json"), "w"), indent=1, sort_keys=True)
     for k, r in rec.items():
         print(k, r.get("build_id", "")[:12], json.dumps(r.get("derived_main")))
+for name in ("lone_trip_audit_scene3.json", "lone_trip_audit_scene1.json", "batch_queue_cost.json", "pmc_shard_records.log"):
+    if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)) > 0:
+        shutil.copy(os.path.join(src, name), os.path.join(dst, name))
 for name, out in (("path_stats.json", "path_stats.json"), ("path_stats_scene1.json", "path_stats_scene1.json"), ("scaling_estimate.jsonl", "scaling_estimate_single_gpu.jsonl"), ("accounting.jsonl", "accounting_by_age_class.jsonl")):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, out))
