@@ -1,6 +1,6 @@
 """Soak run for the grid walk (not a test; run by hand on a GPU box): many random scenes, each probed with adversarial
 rays through rtiow_debug_hit_world -- grid walk vs the exact loop, ray by ray.  Prints one line per scene and a
-summary; exits non-zero on the first mismatch.      python tests/studies/grid_soak.py [n_scenes] [rays_per_family] [first_seed]"""
+summary; exits non-zero on the first mismatch.      python tests/studies/grid_soak.py [n_scenes] [rays_per_family] [first_seed] [max_spheres]"""
 import os
 import sys
 
@@ -15,11 +15,12 @@ from tests.test_grid_plan import _plan  # noqa: E402
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n_each = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
 first_seed = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
+max_n = int(sys.argv[4]) if len(sys.argv) > 4 else 900        # up to ~2000 spheres still get a grid (larger scenes leave LDS): the longest walks, 80-90 cells
 used = rays_total = 0
 for seed in range(n_scenes):
     rng = np.random.default_rng(first_seed + seed)
     prec = 32 if seed % 2 == 0 else 64
-    n = int(rng.integers(40, 900))
+    n = int(rng.integers(40, max_n))
     half = float(np.exp(rng.uniform(np.log(2), np.log(60))))
     centre = rng.uniform(-80, 80, 3) * (seed % 3 == 0)
     rscale = float(np.exp(rng.uniform(np.log(0.02), np.log(1.0))))
