@@ -314,6 +314,7 @@ static int render_begin(rtiow_handle_s* h, int T, bool timed) {
     if (h->precision == 32) rc = launch_render<float>(h, h->cam32, bx, by, wave_tiles, nullptr, true);
     else rc = launch_render<double>(h, h->cam64, bx, by, wave_tiles, nullptr, true);
     if (rc) return rc;
+    if (h->clock_stamps) std::memset(h->clock_stamps, 0, 8 * sizeof(unsigned long long));     // a render that stamps nothing (static schedule) reports no clock, not the last one's
     if (timed && h->warmup_us > 0 && !h->warmed) {        // study knob: the chip's clock ramps under load; this load comes BEFORE the start event
         hipLaunchKernelGGL(clock_warmup_kernel, dim3((unsigned)h->num_cus * 8u), dim3(256), 0, h->stream, (unsigned long long)h->warmup_us * 100ull, (float*)h->work_counter);
         HIP_TRY(h, hipGetLastError());

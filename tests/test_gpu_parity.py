@@ -321,6 +321,28 @@ def test_executable_is_a_drop_in(rt, oracle, tmp_path):
     assert rs.returncode == 0, rs.stderr
     assert open(str(sub / name), "rb").read() == rt.format_ppm(want)
     (sub / name).unlink(); sub.rmdir()
+    # --stats: one JSON line on stderr, stdout untouched; since round 5 with the launches' own event times and the effective shader clock the
+    # launches stamped themselves (rtiow_stats.main_clock_mhz: what tells a 1.7 GHz render from a 2.3 GHz one, profiles/r05/cold_process_study.md)
+    sub = tmp_path / "stats"; sub.mkdir()
+    rs = subprocess.run([exe, "--scene_id", "3", "--width=640", "--height", "360", "--samples", "64", "--bounces=50", "--threads", "8", "--stats", "--ppm_format", "p6"],
+                        capture_output=True, text=True, cwd=str(sub))
+    assert rs.returncode == 0, rs.stderr
+    assert re.fullmatch(r" *\d+\.\d{8}, *\d+\.\d{8}\n", rs.stdout)
+    import json
+    st = json.loads([l for l in rs.stderr.splitlines() if l.startswith("{")][-1])
+    assert st["launch_ms"]["main"] > 0 and st["launch_ms"]["prepass"] > 0 and abs(sum(st["launch_ms"].values()) - st["render_ms"]) < 0.3
+    assert 500 < st["clock_mhz"]["main"] < 3500 and 500 < st["clock_mhz"]["prepass"] < 3500 and st["clock_mhz"]["nominal"] > 0
+    assert 0 < st["clock_mhz"]["main_wave0_ms"] <= st["launch_ms"]["main"] * 1.05
+    for f in os.listdir(str(sub)): (sub / f).unlink()
+    sub.rmdir()
+    # the same figures through the C-ABI
+    with rt.Renderer(0, 32) as r:
+        r.set_camera(rt.camera(32, 640, 360, 64, 50)); r.set_scene(rt.build_scene(3, 32)); r.init_rng(1227)
+        r.render(0)
+        s2 = r.stats()
+        assert 500 < s2["main_clock_mhz"] < 3500 and 500 < s2["prepass_clock_mhz"] < 3500 and 0 < s2["main_wave0_ms"] <= s2["main_ms"] * 1.05
+        r.set_schedule(rt.SCHED_STATIC); r.render(8)
+        assert r.stats()["main_clock_mhz"] == 0          # the static schedule has no persistent wave to stamp
     # defaults (main.cu:45-54) and the double variant's name (GlobalDouble main.cu:351)
     exe64 = exe.replace("float", "double")
     r = subprocess.run([exe64, "--scene_id=3", "--samples=1", "--bounces=2"], capture_output=True, text=True, cwd=str(tmp_path))
