@@ -16,12 +16,46 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 template <class T> struct Trip { T h0, h1, h2, h3, d0, d1, d2, d3; };
 
-// The ray as the sphere loop wants it: fp32 keeps every component splatted over a register
-// pair (the second operand of the packed instructions), fp64 keeps plain scalars.
+// The ray as the sphere loop wants it.  The packed instructions take the ray as their second operand for BOTH spheres of a pair:
+// RTIOW_RAY_BROADCAST (default, round 5) names the component's own register as the low half of a 64-bit operand whose high half is never
+// read -- `op_sel_hi` 0 makes the instruction use the low half for both results -- so no copy of the ray is built at all.  The compiler
+// folds a splat like that by itself when it is made in the basic block that uses it; here the splats are loop-invariant, get hoisted in
+// front of the sphere loop and were materialised there with 14-16 v_mov_b32 per path segment (7 to pin the components, 7 for the high
+// halves: RTIOW_RAY_BROADCAST=0, the form of rounds 1-4).  fp64 keeps plain scalars.
+#ifndef RTIOW_RAY_BROADCAST
+#define RTIOW_RAY_BROADCAST 1
+#endif
 template <class T> struct LoopRay;
+#if RTIOW_RAY_BROADCAST
+template <> struct LoopRay<float> { float ox, oy, oz, dx, dy, dz, a; };
+__device__ __forceinline__ LoopRay<float> make_loop_ray(float ox, float oy, float oz, float dx, float dy, float dz, float a) {
+    return {ox, oy, oz, dx, dy, dz, a};
+}
+// x in the low half of a register pair, the high half undefined (never read)
+__device__ __forceinline__ v2f low_half(float x) {
+    v2f t;          // .y deliberately left unset
+    t.x = x;
+    return t;
+}
+// {c.x - s, c.y - s}, {s * v.x, s * v.y}, {fma(s, v.x, w.x), fma(s, v.y, w.y)}: one IEEE operation per element, as the plain forms
+__device__ __forceinline__ v2f pk_sub_lane(v2f c, float s) {
+    v2f r; asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(c), "v"(low_half(s))); return r;
+}
+__device__ __forceinline__ v2f pk_mul_lane(float s, v2f v) {
+    v2f r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(low_half(s)), "v"(v)); return r;
+}
+__device__ __forceinline__ v2f pk_fma_lane(float s, v2f v, v2f w) {
+    v2f r; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(low_half(s)), "v"(v), "v"(w)); return r;
+}
+// The trip's ray as six opaque registers, pinned IN PLACE where the trip's ray is final (persistent_body): without it the vectoriser keeps
+// O and D as <3 x float> values, and taking one component of those as the low half of a pair goes through scratch memory.  The pinned
+// values replace the state's own, so the pin costs no copy (make_loop_ray's pin of rounds 1-4 kept both alive: 7 v_mov per trip).
+__device__ __forceinline__ void pin_ray(V3<float>& O, V3<float>& D) { asm volatile("" : "+v"(O.x), "+v"(O.y), "+v"(O.z), "+v"(D.x), "+v"(D.y), "+v"(D.z)); }
+__device__ __forceinline__ void pin_ray(V3<double>&, V3<double>&) {}
+#else
+__device__ __forceinline__ void pin_ray(V3<float>&, V3<float>&) {}
+__device__ __forceinline__ void pin_ray(V3<double>&, V3<double>&) {}
 template <> struct LoopRay<float> { v2f ox, oy, oz, dx, dy, dz, aa; float a; };
-template <> struct LoopRay<double> { double ox, oy, oz, dx, dy, dz, a; };
-
 __device__ __forceinline__ LoopRay<float> make_loop_ray(float ox, float oy, float oz, float dx, float dy, float dz, float a) {
     // The empty asm makes each component an opaque VGPR value, so the splats are built with
     // register moves (hipcc otherwise round-trips the ray through scratch to form the pairs).
@@ -32,16 +66,25 @@ __device__ __forceinline__ LoopRay<float> make_loop_ray(float ox, float oy, floa
     r.aa.x = a; r.aa.y = a; r.a = a;
     return r;
 }
+#endif
+template <> struct LoopRay<double> { double ox, oy, oz, dx, dy, dz, a; };
 __device__ __forceinline__ LoopRay<double> make_loop_ray(double ox, double oy, double oz, double dx, double dy, double dz, double a) {
     return {ox, oy, oz, dx, dy, dz, a};
 }
 
 __device__ __forceinline__ void pair_discriminants(v4f lo, v4f hi, const LoopRay<float>& r, v2f& hh, v2f& dd) {
     const v2f cx = {lo.x, lo.y}, cy = {lo.z, lo.w}, cz = {hi.x, hi.y}, r2 = {hi.z, hi.w};
+#if RTIOW_RAY_BROADCAST
+    const v2f ocx = pk_sub_lane(cx, r.ox), ocy = pk_sub_lane(cy, r.oy), ocz = pk_sub_lane(cz, r.oz);  // :42
+    hh = pk_fma_lane(r.dz, ocz, pk_fma_lane(r.dy, ocy, pk_mul_lane(r.dx, ocx)));                       // :44
+    const v2f c = __builtin_elementwise_fma(ocz, ocz, __builtin_elementwise_fma(ocy, ocy, ocx * ocx)) - r2;   // :45
+    dd = __builtin_elementwise_fma(hh, hh, -pk_mul_lane(r.a, c));                                     // :47
+#else
     const v2f ocx = cx - r.ox, ocy = cy - r.oy, ocz = cz - r.oz;                                    // :42
     hh = __builtin_elementwise_fma(r.dz, ocz, __builtin_elementwise_fma(r.dy, ocy, r.dx * ocx));    // :44
     const v2f c = __builtin_elementwise_fma(ocz, ocz, __builtin_elementwise_fma(ocy, ocy, ocx * ocx)) - r2;   // :45
     dd = __builtin_elementwise_fma(hh, hh, -(r.aa * c));                                            // :47
+#endif
 }
 
 __device__ __forceinline__ Trip<float> trip_discriminants(const float* g, int s, const LoopRay<float>& r) {

@@ -238,6 +238,7 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
         if (alive && fresh) RT_PROBE_GEN(T, p, i, j, st.rs);
         if (alive && fresh) { gen_primary(p, i, j, st.rs, st.O, st.D, st.sky_uy); st.atten = {1, 1, 1}; fresh = false; }
         REGION_END(gen, RG_GEN_PRIMARY);
+        pin_ray(st.O, st.D);                                // hit_loop.h: the ray's components as opaque registers, once per trip and in place
         bool terminated = false;
         V3<T> col = {0, 0, 0};
         // hit_world for every lane that still traces (camera.h:84-88), then ONE shade site
