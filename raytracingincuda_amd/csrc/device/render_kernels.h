@@ -221,6 +221,97 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
         }
     };
 
+#ifndef RTIOW_MERGED_ROUNDS
+#define RTIOW_MERGED_ROUNDS 1
+#endif
+    // ---- The rotated trip (fp64, full launches, until the work counter runs dry): hit_world -> shade_front (sky, hit record, the whole dielectric)
+    // -> accumulate + refill -> jitter of the lanes that start a sample -> ONE rejection loop for the lens samples of those lanes and the unit
+    // vectors of the lanes that scatter diffusely (sampling.h merged_rounds) -> primary_finish / shade_back.  The loop below keeps the reference's
+    // order (primary ray first) and runs the two rejection loops one after the other: 2.8 + 2.8 wave-rounds per trip for 24 and 35 lanes, in fp64
+    // 48 and 72 vector instructions each (two generator steps per number) -- 38 % of the trip.  Side by side they take max, not sum, and share four of
+    // six generator steps: vector instructions -5.8 %, fp64 headline 15.1 -> 14.5 ms (profiles/r05/ab_merged_rounds_f64.jsonl).  Every pixel draws the
+    // same numbers in the same order.  When the wave finds the counter exhausted it finishes the trip and goes on in the loop below (cooperative
+    // drain) with the same lane state.  fp32 (in-place generator blocks, 38 / 27 instructions a round): built, -1.8 % instructions, +-0.5 % time, not used.
+    if (RTIOW_MERGED_ROUNDS && !SOLO && sizeof(T) == 8 && p.lane_cap == 64 && (blockDim.x & 63u) == 0) {
+        const bool defocus = !((T)cam_of(p).defocus_angle <= (T)0);
+        // camera.h:160-171 for a lane whose path has ended (a macro: as a lambda it kept `alive` and `fresh` in scratch memory)
+#define RT_END_SAMPLE() do { \
+            ++st.sample; \
+            st.depth = 0; \
+            if (st.sample < S) fresh = true; \
+            else { \
+                PATH_STAT(PS_FINISH_PIXEL); \
+                const auto& c_ = cold_of(p); \
+                if (COUNT) atomicMax(c_.seg_counter + 2, (unsigned long long)cost); \
+                finish_pixel<T>(c_, lp, st, cost); alive = false; \
+            } } while (0)
+        for (;;) {
+            REGION_BEGIN(total);
+            if (alive) PATH_STAT(PS_ITERATION);
+            // ---- hit_world (camera.h:84-88) for every lane that holds a ray and is not in the middle of its rejection loop
+            const bool has_ray = alive && !fresh;
+            const bool need_hit = has_ray && !(RETRY && retry) && st.depth < p.B;
+            if (!(RETRY && retry)) { closest = __builtin_huge_val(); hit = -1; }
+            pin_ray(st.O, st.D);
+            if (COUNT) ++it_normal;
+            REGION_BEGIN(hw);
+            if (need_hit) {
+                const T a = dot3(st.D, st.D);                 // hittable.h:43, ray-invariant
+                hit_world<T, SRC>(p, lds_geom, st.O, st.D, a, closest, hit);
+            }
+            REGION_END(hw, RG_HIT_WORLD);
+            // ---- sky / hit record / dielectric; lambertian and metal stop in front of random_unit_vector
+            REGION_BEGIN(shade);
+            bool need_ruv = false;
+            ShadeCarry<T> sc;
+            sc.nrm = {0, 0, 0}; sc.fuzz = 0; sc.mtype = 0;       // (defined on every path: an undefined value would be live around the whole loop)
+            if (has_ray) {
+                V3<T> col = {0, 0, 0};
+                bool terminated = true;                                              // camera.h:127 at the depth limit
+                if (need_hit || (RETRY && retry)) {
+                    if (need_hit) { ++cost; if (COUNT) ++nseg; }
+                    const int r = shade_front<T>(p, lds_shade, st, closest, hit, col, sc);
+                    terminated = r == SF_TERMINATED;
+                    need_ruv = r == SF_NEED_RUV;
+                }
+                if (terminated) {
+                    st.acc = {st.acc.x + col.x, st.acc.y + col.y, st.acc.z + col.z};   // camera.h:160
+                    RT_END_SAMPLE();
+                }
+            }
+            REGION_END(shade, RG_SHADE);
+            REGION_BEGIN(refill);
+            refill();
+            REGION_END(refill, RG_REFILL);
+            // ---- the sampling step
+            REGION_BEGIN(gen);
+            T jox = 0, joy = 0;
+            const bool starts = alive && fresh;
+            if (starts) { PATH_STAT(PS_GEN_PRIMARY); primary_jitter<T>(st.rs, jox, joy); }
+            int looking = (starts && defocus) ? MR_DISK : (need_ruv ? MR_RUV : MR_CLOSED);
+            if (need_ruv) PATH_STAT(PS_RUV_CALL);
+            T cx = 0, cy = 0, cz = 0, cl = 0;
+            merged_rounds(st.rs, RETRY ? RTIOW_RUV_ROUNDS_PER_ITERATION : 0x7fffffff, looking, cx, cy, cz, cl);
+            if (looking == MR_DISK) { disk_candidate<T>(st.rs, cx, cy); looking = MR_CLOSED; }
+            const bool r_open = looking == MR_RUV;
+            retry = RETRY && r_open;
+            // ---- what follows the rejection loops
+            if (starts) {
+                primary_finish<T>(p, i, j, jox, joy, defocus, cx, cy, st.O, st.D, st.sky_uy);
+                st.atten = {1, 1, 1};
+                fresh = false;
+            }
+            REGION_END(gen, RG_GEN_PRIMARY);
+            REGION_BEGIN(acc);
+            if (need_ruv && !r_open) {
+                if (!shade_back<T>(p, lds_shade, st, sc, closest, hit, cx, cy, cz, cl)) RT_END_SAMPLE();   // the metal absorbed the ray: black (camera.h:117)
+            }
+            REGION_END(acc, RG_ACCUMULATE);
+            REGION_END(total, RG_LOOP_TOTAL);
+            if (exhausted) break;
+        }
+#undef RT_END_SAMPLE
+    }
     for (;;) {
         REGION_BEGIN(total);
         REGION_BEGIN(refill);

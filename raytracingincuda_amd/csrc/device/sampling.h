@@ -48,6 +48,74 @@ template <class T> __device__ __forceinline__ bool random_unit_vector_rounds(Rng
 __device__ __forceinline__ void keep_scalar(float& a, float& b, float& c, float& d, float& e, float& f) { asm volatile("" : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e), "+s"(f)); }
 __device__ __forceinline__ void keep_scalar(double& a, double& b, double& c, double& d, double& e, double& f) { asm volatile("" : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e), "+s"(f)); }
 
+// ---- The rotated trip of persistent_body (RTIOW_MERGED_ROUNDS, fp64): gen_primary and shade_step cut at their rejection loops, so that ONE loop
+// serves both.  A lane is looking for a unit-vector candidate (vec3.h:117-125: three numbers a round) or for a lens sample (vec3.h:109-115: two
+// numbers a round).  Both form x = 2 u0 - 1, y = 2 u1 - 1 and fma(y, y, x x) the same way, so a round draws two numbers for every open lane and
+// the third, z and fma(z, z, .) for the unit-vector lanes only -- and a trip runs max(rounds) of them instead of the sum of two loops' rounds.
+// At most `rounds` rounds; a lane still open keeps its kind.  A pixel's draws and their order are unchanged: the same steps of its generator, the
+// same arithmetic on the same draws.  (fp32 was built too -- a fused in-place generator block with the third step under a narrowed exec mask --
+// and measured -1.8 % vector instructions, +-0.5 % time: profiles/experiments/r05_merged_rejection_rounds.md; the fp32 kernels keep one loop.)
+enum { MR_CLOSED = 0, MR_DISK = 1, MR_RUV = 2 };       // what a lane is looking for (ONE variable: two flags updated in the arms of an if went through scratch memory)
+__device__ __forceinline__ void merged_rounds(Rng&, int, int&, float&, float&, float&, float&) {}   // never called: persistent_body takes the rotated trip for fp64 only
+// fp64: curand_uniform_double takes two steps of the generator per number (xorwow.h), so a lens round is four steps and a unit-vector round six -- the
+// rounds are the heaviest blocks of the fp64 trip (72 and 48 vector instructions); merged, four of the six steps and two of the three conversions are shared.
+__device__ __forceinline__ void merged_rounds(Rng& s, int rounds, int& kind, double& x, double& y, double& z, double& lensq) {
+    typedef double T;
+#pragma unroll 3        // (rolled: the same time; two or four rounds per trip: +3.4 / +2.6 %, profiles/r05/merged_rounds_f64_variants.jsonl)
+    for (int r = 0; r < rounds; ++r) {
+        if (__builtin_amdgcn_ballot_w64(kind != MR_CLOSED) == 0) break;
+        if (kind != MR_CLOSED) {
+            const bool three = kind == MR_RUV;
+            if (three) PATH_STAT(PS_RUV_ROUND); else PATH_STAT(PS_DISK_ROUND);
+            const double u0 = Real<double>::uniform(s);
+            const double u1 = Real<double>::uniform(s);
+            x = RT_FMA(u0, 2.0, -1.0);
+            y = RT_FMA(u1, 2.0, -1.0);
+            const double l2 = RT_FMA(y, y, x * x);
+            bool accepted = l2 < 1.0;                                               // vec3.h:113
+            if (three) {
+                const double u2 = Real<double>::uniform(s);
+                z = RT_FMA(u2, 2.0, -1.0);
+                lensq = RT_FMA(z, z, l2);
+                accepted = Real<double>::ruv_eps < lensq && lensq <= 1.0;             // vec3.h:125
+            }
+            kind = accepted ? MR_CLOSED : kind;
+        }
+    }
+}
+// the lens loop of a lane that is still open behind the merged rounds (one lane in a hundred after three rounds)
+template <class T> __device__ __forceinline__ void disk_candidate(Rng& s, T& px, T& py) {
+    for (;;) {
+        PATH_STAT(PS_DISK_ROUND);
+        T u0, u1;
+        Real<T>::uniform2(s, u0, u1);
+        px = RT_FMA((T)2, u0, (T)-1);
+        py = RT_FMA((T)2, u1, (T)-1);
+        if (RT_FMA(py, py, px * px) < (T)1) break;
+    }
+}
+// camera.h:145-146 (the two jitter draws, first argument first) and camera.h:147-155 once the lens sample is known.
+template <class T> __device__ __forceinline__ void primary_jitter(Rng& s, T& ox, T& oy) {
+    ox = Real<T>::uniform(s) - (T)0.5;
+    oy = Real<T>::uniform(s) - (T)0.5;
+}
+template <class T>
+__device__ __forceinline__ void primary_finish(const RenderParams<T>& p, int i, int j, T ox, T oy, bool defocus, T px, T py, V3<T>& O, V3<T>& D, T& sky_uy) {
+    const auto& c = cam_of(p);
+    const T fi = (T)i + ox, fj = (T)j + oy;
+    const V3<T> ps = madd3(fj, V3<T>{c.dv.x, c.dv.y, c.dv.z}, madd3(fi, V3<T>{c.du.x, c.du.y, c.du.z}, V3<T>{c.pixel00.x, c.pixel00.y, c.pixel00.z}));
+    const V3<T> ctr = {c.center.x, c.center.y, c.center.z};
+    V3<T> org = ctr;
+    if (defocus) org = madd3(py, V3<T>{c.ddv.x, c.ddv.y, c.ddv.z}, madd3(px, V3<T>{c.ddu.x, c.ddu.y, c.ddu.z}, ctr));
+    O = org;
+    D = {ps.x - org.x, ps.y - org.y, ps.z - org.z};
+    const T dd = dot3(D, D);
+    T inv;
+    if (p.range_flags & 1) inv = inv_sqrt_accepted(dd);   // wave-uniform choice, same bits
+    else inv = (T)1 / Real<T>::sqrt(dd);
+    sky_uy = inv * D.y;
+}
+
 // One primary ray: camera.h:145-155 (+ :73-76, vec3.h:109-115).  Also returns the y
 // component of the PRIMARY ray's unit direction, all the sky term needs (camera.h:121).
 template <class T>
