@@ -1,6 +1,6 @@
 """Execution profile of the render kernel (needs `python -m raytracingincuda_amd.build --stats`):
 wave-level executions and active lanes of every divergent region per wave-iteration.
-Usage: path_stats_probe.py [scene_id [W H S B]]"""
+Usage: path_stats_probe.py [scene_id [W H S B]]      (RTIOW_PROBE_PREC=64: the fp64 kernels)"""
 import ctypes, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracingincuda_amd as rt
@@ -14,7 +14,8 @@ W, H, S, B = (int(x) for x in a[1:5]) if len(a) >= 5 else (1920, 1080, 100, 50)
 names = ["iteration", "ruv_call", "ruv_round", "disk_round", "gen_primary", "shade_hit", "sky", "dielectric", "metal",
          "exact_block", "finish_call", "ieee_block", "second_div", "schlick_draw", "refill", "finish_pixel", "grid_step",
          "walk_step_1", "walk_step_2", "walk_step_3", "walk_step_4", "walk_step_5_8", "walk_step_9_up", "walk_entered", "cell_second_pair"]
-r = rt.Renderer(0, 32); r.set_camera(rt.camera(32, W, H, S, B)); r.set_scene(rt.build_scene(scene, 32))
+prec = int(os.environ.get("RTIOW_PROBE_PREC", "32"))
+r = rt.Renderer(0, prec); r.set_camera(rt.camera(prec, W, H, S, B)); r.set_scene(rt.build_scene(scene, prec))
 sched = int(os.environ.get("RTIOW_PROBE_SCHED", "2"))
 r.init_rng(1227); r.set_schedule(sched, 0)
 lib = api.load_hip_library()
@@ -28,7 +29,7 @@ assert lib.rtiow_debug_region_cycles(rbuf, len(rbuf), 0) == 0
 assert lib.rtiow_debug_path_stats(buf, len(buf), 0) == 0
 v = list(buf)
 it = float(v[0])
-out = {"config": "scene %d %dx%d %d spp %d bounces fp32, schedule %d (all launches together)" % (scene, W, H, S, B, sched), "wave_iterations": int(it),
+out = {"config": "scene %d %dx%d %d spp %d bounces fp%d, schedule %d (all launches together)" % (scene, W, H, S, B, prec, sched), "wave_iterations": int(it),
        "lanes_per_iteration": round(v[1] / it, 2), "per_wave_iteration": {}}
 for k, n in enumerate(names[1:], 1):
     out["per_wave_iteration"][n] = {"wave_executions": round(v[2 * k] / it, 3), "active_lanes_each": round(v[2 * k + 1] / max(v[2 * k], 1), 1)}
