@@ -555,6 +555,28 @@ def test_grid_walk_on_degenerate_rays(rt, oracle, prec):
         assert _same_bits(a, b), (center, direction, "spread")
 
 
+@pytest.mark.parametrize("S,B,defocus", [(3, 6, True), (2, 8, False), (1, 1, True), (24, 5, True)])
+def test_rotated_fp64_trip_matches_the_oracle(rt, oracle, S, B, defocus):
+    """The fp64 kernels run a ROTATED trip (one rejection loop for lens samples and unit vectors) while the launch fills
+    every lane -- frames of at least 64 pixels per resident wave, which the small parametrised frames above are not.  640 x 448 takes it
+    (4 480 pools for 4 096 resident waves); with and without a lens (no lens: the loop serves unit vectors only and a new sample starts
+    without a draw), one sample of one segment (every lane starts a sample in every trip), and a two-phase frame (prepass and main launch
+    both rotated, the state parked between them)."""
+    W, H = 640, 448
+    sc = rt.build_scene(3, 64)
+    cam = rt.camera(64, W, H, S, B)
+    if not defocus:
+        for k in range(3):
+            cam.defocus_disk_u[k] = 0.0; cam.defocus_disk_v[k] = 0.0
+        cam.defocus_angle = 0.0
+    got, st = _render_cam(rt, 64, sc, cam, rt.SCENE_GRID)
+    assert W * H // 64 >= 256 * 4 * 4        # at least one 64-pixel pool per resident fp64 wave (four per SIMD): every lane takes pixels
+    want, _ = oracle.render(64, compact(sc), cam, 1227)
+    assert _same_bits(got, want), (S, B, defocus)
+    again, _ = _render_cam(rt, 64, sc, cam, rt.SCENE_GRID, sched=rt.SCHED_STATIC)       # the reference's own launch geometry: no persistent loop at all
+    assert _same_bits(again, want)
+
+
 def test_primary_ray_normalisation_paths_match_the_oracle(rt, oracle):
     """gen_primary takes 1/sqrt(|D|^2) through the short in-range sequence when the host can bound |D| for the
     whole frame (primary_rays_in_range) and through the compiler's full IEEE sequence otherwise.  The same view
