@@ -232,7 +232,10 @@ __device__ __forceinline__ void persistent_body(const RenderParams<T>& p) {
     // six generator steps: vector instructions -5.8 %, fp64 headline 15.1 -> 14.5 ms (profiles/r05/ab_merged_rounds_f64.jsonl).  Every pixel draws the
     // same numbers in the same order.  When the wave finds the counter exhausted it finishes the trip and goes on in the loop below (cooperative
     // drain) with the same lane state.  fp32 (in-place generator blocks, 38 / 27 instructions a round): built, -1.8 % instructions, +-0.5 % time, not used.
-    if (RTIOW_MERGED_ROUNDS && !SOLO && sizeof(T) == 8 && p.lane_cap == 64 && (blockDim.x & 63u) == 0) {
+#ifndef RTIOW_MERGED_ROUNDS_SOLO_KERNEL
+#define RTIOW_MERGED_ROUNDS_SOLO_KERNEL 1     // the solo kernel's ordinary waves take the rotated trip too (its solo waves need the cooperative hit_world of the loop below):
+#endif                                        // fp64 1280 x 720 -2.7 %, half-frame shard -3.4 %, 960 x 540 -2.3 % (profiles/r05/ab_rotated_trip_in_solo_kernel_f64.jsonl)
+    if (RTIOW_MERGED_ROUNDS && (!SOLO || (RTIOW_MERGED_ROUNDS_SOLO_KERNEL && !solo)) && sizeof(T) == 8 && p.lane_cap == 64 && (blockDim.x & 63u) == 0) {
         const bool defocus = !((T)cam_of(p).defocus_angle <= (T)0);
         // camera.h:160-171 for a lane whose path has ended (a macro: as a lambda it kept `alive` and `fresh` in scratch memory)
 #define RT_END_SAMPLE() do { \
